@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the stereo hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Metric (BASELINE.json): disparity Mpix*disp/s = pixels x candidate positions
+evaluated per second.  A step is one pass of the dense disparity scan over one
+synthetic rectified pair of BASELINE config 2 (2880x1988, 256 disparities) per
+GPU; inputs are resident in HBM before the timed region.  Ranks each own their
+pair (pair sharding, no data-path collective), so scaling is weak.
+
+The JSON line also carries the roofline of the dominant kernel, the CPU
+baseline (oracle restatement on a bounded sample, rank 0 at N=1 only) and an
+"extra" object with the other kernels of the path (reference-mode scan,
+rectification warp, descriptor matching), each measured with HIP events.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# MI355X constants (/opt/skills/guides/MI355X_MICROARCH.md)
+CUS = 256
+CLOCK_HZ = 2.4e9
+VALU_LANEOPS = CUS * 4 * 32 * CLOCK_HZ      # 4 SIMD-32 per CU, one lane-op per lane per clock
+HBM_PEAK_GBS = 8000.0
+MFMA_F32_TFLOPS = 157.3
+
+W, H, D, WIN = 2880, 1988, 256, 9           # BASELINE config 2, 9x9 SAD window
+OPS_PER_UNIT_WINDOWED = 7                   # sliding column/row sums
+OPS_PER_UNIT_WIN1 = 3                       # subtract, abs, compare-select
+
+
+def event_time_ms(torch, fn, steps, warmup):
+    """Average ms per call of fn over `steps` calls, HIP events on the current stream."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def units_evaluated(w, h, d):
+    """Candidate positions actually evaluated: pixel x has min(x+1, d) candidates."""
+    d = min(d, w)
+    per_row = d * (w - d) + d * (d + 1) // 2
+    return per_row * h
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary kernels")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--match-n", type=int, default=32768, help="n1 = n2 of the matching leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import stereo_amd
+    from stereo_amd import synth, api
+
+    ctx = stereo_amd.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # ---- headline: windowed bounded-D disparity scan, one pair per GPU ----------
+    left, right = synth.rectified_pair(2024 + rank, H, W, D)
+    d_l = torch.from_numpy(left).cuda()
+    d_r = torch.from_numpy(right).cuda()
+    d_o = torch.empty_like(d_l)
+
+    def step():
+        ctx.disparity_dev(d_l, d_r, d_o, win=WIN, max_disp=D, cost_mode=api.COST_SAD)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = e0.elapsed_time(e1) / args.steps  # one launch per step on this stream
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    units = units_evaluated(W, H, D)
+    value = units * world * args.steps / elapsed / 1e6
+
+    out = {
+        "metric": "disparity Mpix*disp/s",
+        "value": value,
+        "unit": "Mpix*disp/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE config 2: %dx%d u8 rectified pair per GPU, %d disparities, "
+                        "%dx%d SAD window (D1-ext), pair-sharded" % (W, H, D, WIN, WIN),
+            "pairs_per_step": world, "width": W, "height": H, "max_disp": D, "win": WIN,
+            "units_per_pair": units, "parallelism": "pairs x%d" % world,
+        },
+    }
+    achieved = units * OPS_PER_UNIT_WINDOWED / (kernel_ms * 1e-3)
+    out["roofline"] = {
+        "kernel": "disparity scan, %dx%d SAD, D=%d" % (WIN, WIN, D),
+        "bound": "valu",
+        "achieved": achieved / 1e12,
+        "peak": VALU_LANEOPS / 1e12,
+        "unit": "Tlane-op/s",
+        "frac": achieved / VALU_LANEOPS,
+        "traffic": None,
+        "model": "%d integer lane-ops per (pixel,candidate) unit (SURVEY 8d); peak = %d CU x 4 SIMD x 32 "
+                 "lanes x %.1f GHz" % (OPS_PER_UNIT_WINDOWED, CUS, CLOCK_HZ / 1e9),
+        "kernel_ms": kernel_ms,
+        "hbm_GBps_algorithmic": 3.0 * W * H / (kernel_ms * 1e-3) / 1e9,
+    }
+
+    # ---- secondary kernels (rank 0 only, outside the timed region) -----------
+    extra = {}
+    if rank == 0 and not args.no_extra:
+        ks, kw = max(3, args.steps // 4), 1
+        # reference mode: 1x1 window, whole-row search (bit-exact vs the reference)
+        ms = event_time_ms(torch, lambda: ctx.disparity_dev(d_l, d_r, d_o, win=1, max_disp=0), ks, kw)
+        u = W * W * H
+        extra["disparity_reference_mode"] = {
+            "workload": "%dx%d, 1x1 window, whole-row search (ComputeDepthImage as written)" % (W, H),
+            "ms": ms, "Mpix_disp_per_s": u / (ms * 1e-3) / 1e6,
+            "roofline": {"bound": "valu", "achieved": u * OPS_PER_UNIT_WIN1 / (ms * 1e-3) / 1e12,
+                         "peak": VALU_LANEOPS / 1e12, "unit": "Tlane-op/s",
+                         "frac": u * OPS_PER_UNIT_WIN1 / (ms * 1e-3) / VALU_LANEOPS},
+        }
+        ms = event_time_ms(torch, lambda: ctx.disparity_dev(d_l, d_r, d_o, win=1, max_disp=D), ks, kw)
+        extra["disparity_win1_d256"] = {
+            "workload": "%dx%d, 1x1 window, %d disparities" % (W, H, D),
+            "ms": ms, "Mpix_disp_per_s": units / (ms * 1e-3) / 1e6,
+            "roofline": {"bound": "valu", "achieved": units * OPS_PER_UNIT_WIN1 / (ms * 1e-3) / 1e12,
+                         "peak": VALU_LANEOPS / 1e12, "unit": "Tlane-op/s",
+                         "frac": units * OPS_PER_UNIT_WIN1 / (ms * 1e-3) / VALU_LANEOPS},
+        }
+        # rectification warp: batch of 8 x 1080p
+        nimg, rh, rw = 8, 1080, 1920
+        src = torch.from_numpy(np.stack([synth.texture(70 + k, rh, rw) for k in range(2)])).cuda()
+        src = src.repeat(nimg // 2, 1, 1).contiguous()
+        dstt = torch.zeros_like(src)
+        Hinv = np.stack([ctx.invert_homography(synth.homography(80 + k, rw, rh)).reshape(9)
+                         for k in range(nimg)])
+        ms = event_time_ms(torch, lambda: ctx.rectify_dev(src, dstt, Hinv, api.RECT_DST_IS_ZERO), ks, kw)
+        gbs = 2.0 * nimg * rh * rw / (ms * 1e-3) / 1e9
+        extra["rectify"] = {
+            "workload": "%d x %dx%d u8, K R K^-1 homographies, zero-initialised destination" % (nimg, rw, rh),
+            "ms": ms, "Mpix_per_s": nimg * rh * rw / (ms * 1e-3) / 1e6,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "bytes_per_pixel": 2},
+        }
+        # descriptor matching
+        n = args.match_n
+        d1, s1, d2, s2 = synth.descriptor_sets(42, n, n)
+        td1, ts1 = torch.from_numpy(d1).cuda(), torch.from_numpy(s1).cuda()
+        td2, ts2 = torch.from_numpy(d2).cuda(), torch.from_numpy(s2).cuda()
+        oc = torch.empty(n, dtype=torch.int32, device="cuda")
+        os_ = torch.empty(n, dtype=torch.int32, device="cuda")
+        om = torch.empty(n, dtype=torch.float32, device="cuda")
+        od = torch.empty(n, dtype=torch.float32, device="cuda")
+        ot = torch.empty(n, dtype=torch.uint8, device="cuda")
+        ms = event_time_ms(torch, lambda: ctx.match_dev(td1, ts1, td2, ts2, 1000.0, oc, os_, om, od, ot), 2, 1)
+        flops = 2.0 * n * n * 128
+        extra["match"] = {
+            "workload": "%d x %d 128-d fp32 SIFT-like descriptors (BASELINE config 5 shape, scaled)" % (n, n),
+            "ms": ms, "matched_descriptors_per_s": n / (ms * 1e-3),
+            "pair_evaluations_per_s": float(n) * n / (ms * 1e-3),
+            "accepted": int((ot == 3).sum().item()),
+            "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_F32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / MFMA_F32_TFLOPS,
+                         "dtype": "f32"},
+        }
+    if extra:
+        out["extra"] = extra
+
+    # ---- CPU baseline: the oracle restatement on a bounded sample ------------
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import oracle as orc
+        rows = 480
+        band_l, band_r = left[:rows], right[:rows]
+        t0 = time.perf_counter()
+        ref = orc.disparity_ext(band_l, band_r, WIN, D, 0, sliding=True)
+        dt = time.perf_counter() - t0
+        got = d_o  # last extra leg may have overwritten it: recompute the headline output
+        ctx.disparity_dev(d_l, d_r, d_o, win=WIN, max_disp=D, cost_mode=api.COST_SAD)
+        torch.cuda.synchronize()
+        same = bool((d_o[:rows - WIN // 2].cpu().numpy() == ref[:rows - WIN // 2]).all())
+        out["cpu_baseline"] = {
+            "value": units_evaluated(W, rows, D) / dt / 1e6,
+            "unit": "Mpix*disp/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": "oracle_disparity_ext_sliding on the first %d of %d rows of the same pair "
+                      "(%.1f s, single thread; the reference is single-threaded)" % (rows, H, dt),
+            "matches_gpu_on_sample": same,
+        }
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,179 @@
+/*
+ * stereo_hip.h -- C ABI of libstereo_hip.so, the MI355X (gfx950) implementation
+ * of the three data-parallel stages of dmckinnon/stereo:
+ *
+ *   M  MatchDescriptors     stereo/Features.h:195-196   (body Features.cpp:1020-1079)
+ *   R  RectifyImage         stereo/Stereography.h:48-51 (body Stereography.cpp:596-631)
+ *   D  ComputeDepthImage    stereo/Stereography.h:53-55 (body Stereography.cpp:649-691)
+ *
+ * The reference has no FFI: its boundary is those three C++ free functions,
+ * called once each from main() (stereo/main.cpp:207, :363-369, :380).  The
+ * drop-in adapter stereo_amd/adapter/stereo_dropin.hpp re-implements the three
+ * signatures on top of this ABI.
+ *
+ * Conventions
+ *   - plain C types only; no exceptions cross the boundary
+ *   - return 0 on success, STX_ERR_* (< 0) for argument/usage errors, a
+ *     positive hipError_t when a HIP call fails (stx_error_string decodes both)
+ *   - one context per (thread, GPU); a context is bound to one device and one
+ *     stream; calls on one context must not overlap
+ *   - "host" entry points take host pointers, copy in, run, copy out and block;
+ *     "_dev" entry points take device pointers, enqueue on the context's stream
+ *     and return without synchronising (use stx_synchronize)
+ *   - images are single-channel uint8, row-major, row pitch in BYTES
+ */
+#ifndef STEREO_HIP_H
+#define STEREO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STX_VERSION 100 /* 0.1.0 */
+
+#define STX_DESC_LEN 128 /* DESC_LENGTH, stereo/Features.h:46 */
+
+/* error codes (negative); positive return values are hipError_t */
+#define STX_OK 0
+#define STX_ERR_INVALID_ARG (-1)
+#define STX_ERR_UNSUPPORTED (-2)
+#define STX_ERR_NO_DEVICE (-3)
+#define STX_ERR_HOST_OOM (-4)
+#define STX_ERR_TOO_LARGE (-5)
+
+/* per-query outcome written to status[] by stx_match* */
+#define STX_MATCH_FAILED 0   /* closest or secondClosest unset: the reference prints
+                                "Error: failed to match feature <i>" (Features.cpp:1049-1054) */
+#define STX_MATCH_SCORE 1    /* |score1[i]-score2[closest]| > dist_limit (Features.cpp:1057-1060) */
+#define STX_MATCH_RATIO 2    /* ratio test failed (Features.cpp:1062-1067) */
+#define STX_MATCH_ACCEPTED 3 /* the reference pushes the pair (Features.cpp:1069-1074) */
+
+/* cost_mode of the disparity scan */
+#define STX_COST_SAD 0
+#define STX_COST_SSD 1
+
+/* flags of stx_rectify_u8* */
+#define STX_RECT_PRESERVE_DST 0 /* pixels that miss keep their prior value (reference behaviour) */
+#define STX_RECT_DST_IS_ZERO 1  /* caller guarantees dst is all zero (as main.cpp:362,366 does):
+                                   misses are written as 0 and dst is never read */
+
+/* matching algorithm selector (stx_set_match_algo) */
+#define STX_MATCH_AUTO 0  /* exact scan for small problems, MFMA prefilter otherwise */
+#define STX_MATCH_EXACT 1 /* VALU scan in reference operation order */
+#define STX_MATCH_MFMA 2  /* fp32 MFMA prefilter + exact replay of the running-minimum records */
+
+typedef struct stx_ctx stx_ctx;
+
+/* ---- library / context ------------------------------------------------- */
+
+int stx_version(void);
+const char *stx_error_string(int code);
+
+/* Number of HIP devices visible to this process (<0: error). */
+int stx_device_count(void);
+
+/* Create a context on HIP device `device`.  The launch stream defaults to the
+ * NULL stream. */
+int stx_create(stx_ctx **out, int device);
+void stx_destroy(stx_ctx *ctx);
+
+/* Use `hip_stream` (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream)
+ * for every launch and copy of this context.  The stream is not owned. */
+int stx_set_stream(stx_ctx *ctx, void *hip_stream);
+int stx_synchronize(stx_ctx *ctx);
+
+/* Choose the matching algorithm (STX_MATCH_*).  All algorithms give identical
+ * outputs; this exists for testing and benchmarking. */
+int stx_set_match_algo(stx_ctx *ctx, int algo);
+
+/* ---- M: descriptor matching --------------------------------------------
+ * Replaces MatchDescriptors (Features.h:195-196).  desc1/desc2 are [n][128]
+ * fp32 row-major (Feature::desc, Features.h:47-50,58), score* are
+ * Feature::score (Features.h:56).  dist_limit is distLimitBetweenMatches
+ * (main.cpp:207 passes MAX_DIST_BETWEEN_MATCHES = 1000.f, Features.h:34).
+ * Per query i of list1 (any output pointer may be NULL):
+ *   closest[i], second[i]  final closest / secondClosest (Features.cpp:1033-1047), -1 = unset
+ *   min_dist[i]            final minDist, -1.0f when n2 == 0
+ *   second_dist[i]         distance to list2[second[i]], -1.0f when second[i] < 0
+ *   status[i]              STX_MATCH_*
+ * The adapter turns these into the reference's vector of (Feature, Feature)
+ * pairs in ascending i and prints the reference's failure line. */
+int stx_match(stx_ctx *ctx, const float *desc1, const float *score1, int n1,
+              const float *desc2, const float *score2, int n2, float dist_limit,
+              int32_t *closest, int32_t *second, float *min_dist,
+              float *second_dist, uint8_t *status);
+
+/* Same with every array resident in device memory; asynchronous. */
+int stx_match_dev(stx_ctx *ctx, const float *d_desc1, const float *d_score1, int n1,
+                  const float *d_desc2, const float *d_score2, int n2,
+                  float dist_limit, int32_t *d_closest, int32_t *d_second,
+                  float *d_min_dist, float *d_second_dist, uint8_t *d_status);
+
+/* ---- R: rectification warp ---------------------------------------------
+ * Host-side helper: H.inverse() as Eigen::Matrix3f computes it at
+ * Stereography.cpp:617 (cofactors / determinant, fp32).  Row-major 3x3. */
+int stx_invert_homography(const float H[9], float Hinv[9]);
+
+/* Replaces the loop of RectifyImage (Stereography.cpp:612-630) for one image.
+ * Hinv is the row-major INVERSE homography (rectified -> original), i.e.
+ * stx_invert_homography(H) of the H the reference passes.  dst is in/out. */
+int stx_rectify_u8(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h,
+                   size_t src_stride, uint8_t *dst, int dst_w, int dst_h,
+                   size_t dst_stride, const float Hinv[9], int flags);
+
+/* Batched, device-resident form: n_images images, image k at
+ * d_src + k*src_image_stride / d_dst + k*dst_image_stride, warped with
+ * Hinv[9*k .. 9*k+8] (host array).  Asynchronous. */
+int stx_rectify_u8_dev(stx_ctx *ctx, const uint8_t *d_src, int src_w, int src_h,
+                       size_t src_stride, size_t src_image_stride, uint8_t *d_dst,
+                       int dst_w, int dst_h, size_t dst_stride,
+                       size_t dst_image_stride, const float *Hinv, int n_images,
+                       int flags);
+
+/* ---- D: dense disparity scan -------------------------------------------
+ * Replaces ComputeDepthImage (Stereography.h:53-55).  Reference mode is
+ * win = 1, max_disp = 0, cost_mode = STX_COST_SAD: 1x1 absolute difference,
+ * every column of the same row of img1 is a candidate, zero pixels are skipped,
+ * first minimum wins, output |xBest - x| mod 256 (Stereography.cpp:664-688).
+ *
+ * win > 1 or max_disp > 0 select this library's generalisation (D1-ext,
+ * DESIGN.md): odd win x win SAD/SSD window with out-of-image taps excluded,
+ * candidates x1 in [max(0, x-max_disp+1), x] scanned in ascending x1, initial
+ * best 255*win^2 (65025*win^2 for SSD), strict <.  max_disp = 0 requires win = 1.
+ * The reference's size-mismatch branch (Stereography.cpp:655-659) is handled
+ * by the adapter, which owns both Mats. */
+int stx_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int w,
+                     int h, size_t stride, int win, int max_disp, int cost_mode,
+                     uint8_t *out, size_t out_stride);
+
+/* uint16 output (value mod 65536) for max_disp > 256; out_stride in bytes. */
+int stx_disparity_u16(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int w,
+                      int h, size_t stride, int win, int max_disp, int cost_mode,
+                      uint16_t *out, size_t out_stride);
+
+/* Batched, device-resident form: pair k at d_img* + k*pair_stride, output k at
+ * d_out + k*out_pair_stride.  out_bytes = 1 (uint8) or 2 (uint16); strides in
+ * bytes.  Asynchronous. */
+int stx_disparity_dev(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_img1,
+                      int n_pairs, int w, int h, size_t stride, size_t pair_stride,
+                      int win, int max_disp, int cost_mode, void *d_out,
+                      size_t out_stride, size_t out_pair_stride, int out_bytes);
+
+/* Row-band form for sharding one large pair over several GPUs:
+ * computes output rows [row0, row0+rows) only; img pointers and h describe the
+ * rows this process holds, [band_row0, band_row0+h) of the full image, which
+ * must include win/2 halo rows where the full image has them.  full_h is the
+ * full image height.  d_out points at output row `row0`. */
+int stx_disparity_rowband_dev(stx_ctx *ctx, const uint8_t *d_img0,
+                              const uint8_t *d_img1, int w, int h, int band_row0,
+                              int full_h, size_t stride, int row0, int rows, int win,
+                              int max_disp, int cost_mode, void *d_out,
+                              size_t out_stride, int out_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEREO_HIP_H */

@@ -1,0 +1,104 @@
+"""ctypes wrapper of oracle/liboracle.so (the CPU restatement).
+
+TEST INFRASTRUCTURE.  May be imported only by tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg -- never by the stereo_amd package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "stereo_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "liboracle.so"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.oracle_descriptor_distance.restype = C.c_float
+        _lib.oracle_bilinear.restype = C.c_uint8
+    return _lib
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return float(lib().oracle_descriptor_distance(_p(a), _p(b)))
+
+
+def match(desc1, score1, desc2, score2, dist_limit=1000.0):
+    desc1 = np.ascontiguousarray(desc1, np.float32).reshape(-1, 128)
+    desc2 = np.ascontiguousarray(desc2, np.float32).reshape(-1, 128)
+    score1 = np.ascontiguousarray(score1, np.float32)
+    score2 = np.ascontiguousarray(score2, np.float32)
+    n1, n2 = len(desc1), len(desc2)
+    closest = np.full(n1, -7, np.int32)
+    second = np.full(n1, -7, np.int32)
+    md = np.zeros(n1, np.float32)
+    sd = np.zeros(n1, np.float32)
+    st = np.zeros(n1, np.uint8)
+    lib().oracle_match(_p(desc1), _p(score1), n1, _p(desc2), _p(score2), n2,
+                       C.c_float(dist_limit), _p(closest), _p(second), _p(md), _p(sd), _p(st))
+    return closest, second, md, sd, st
+
+
+def invert3x3(H):
+    H = np.ascontiguousarray(H, np.float32).reshape(9)
+    out = np.empty(9, np.float32)
+    lib().oracle_invert3x3(_p(H), _p(out))
+    return out.reshape(3, 3)
+
+
+def bilinear(img, x, y):
+    img = np.ascontiguousarray(img, np.uint8)
+    return int(lib().oracle_bilinear(_p(img), C.c_size_t(img.strides[0]), C.c_float(x), C.c_float(y)))
+
+
+def rectify(src, dst, Hinv):
+    src = np.ascontiguousarray(src, np.uint8)
+    assert dst.flags.c_contiguous and dst.dtype == np.uint8
+    Hinv = np.ascontiguousarray(Hinv, np.float32).reshape(9)
+    lib().oracle_rectify(_p(src), src.shape[1], src.shape[0], C.c_size_t(max(src.shape[1], 1)),
+                         _p(dst), dst.shape[1], dst.shape[0], C.c_size_t(max(dst.shape[1], 1)),
+                         _p(Hinv))
+    return dst
+
+
+def disparity_ref(img0, img1):
+    img0 = np.ascontiguousarray(img0, np.uint8)
+    img1 = np.ascontiguousarray(img1, np.uint8)
+    h, w = img0.shape
+    out = np.full((h, w), 0xAA, np.uint8)
+    lib().oracle_disparity_ref(_p(img0), _p(img1), w, h, C.c_size_t(max(w, 1)), _p(out),
+                               C.c_size_t(max(w, 1)))
+    return out
+
+
+def disparity_ext(img0, img1, win, max_disp, cost_mode=0, out_dtype=np.uint8, sliding=False):
+    img0 = np.ascontiguousarray(img0, np.uint8)
+    img1 = np.ascontiguousarray(img1, np.uint8)
+    h, w = img0.shape
+    dt = np.dtype(out_dtype)
+    out = np.zeros((h, w), dt)
+    fn = lib().oracle_disparity_ext_sliding if sliding else lib().oracle_disparity_ext
+    rc = fn(_p(img0), _p(img1), w, h, C.c_size_t(max(w, 1)), int(win), int(max_disp),
+            int(cost_mode), _p(out), C.c_size_t(max(w, 1) * dt.itemsize), dt.itemsize)
+    if rc != 0:
+        raise ValueError("oracle_disparity_ext: invalid arguments")
+    return out

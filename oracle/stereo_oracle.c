@@ -1,0 +1,358 @@
+/*
+ * stereo_oracle.c -- CPU restatement of dmckinnon/stereo's three hot-path
+ * functions.  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see stereo_oracle.h).
+ *
+ * Every function cites the reference lines it follows.  Nothing here is a copy
+ * of reference text: the reference operates on cv::Mat / Eigen / std::vector,
+ * this file on plain pointers, and the arithmetic is restated statement by
+ * statement so that the rounding sequence is the same.
+ *
+ * Must be compiled with -ffp-contract=off (no FMA) and without -ffast-math.
+ */
+#include "stereo_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ M --- */
+
+/* Features.cpp:1007-1018 then :806-815.  aVec[i] -= bVec[i] is one rounded
+ * fp32 subtraction; norm += v[i]*v[i] is a rounded product followed by a
+ * rounded sum into a single float accumulator, i ascending; sqrt is the
+ * correctly rounded float square root. */
+float oracle_descriptor_distance(const float *a, const float *b)
+{
+    float norm = 0.0f; /* strict IEEE build: gcc may not reassociate this sum */
+    for (int i = 0; i < ORACLE_DESC_LEN; ++i) {
+        float diff = a[i] - b[i];
+        float sq = diff * diff;
+        norm = norm + sq;
+    }
+    return sqrtf(norm);
+}
+
+/* Features.cpp:1020-1079 */
+int oracle_match(const float *desc1, const float *score1, int n1,
+                 const float *desc2, const float *score2, int n2,
+                 float dist_limit, int32_t *closest_out, int32_t *second_out,
+                 float *min_dist_out, float *second_dist_out, uint8_t *status_out)
+{
+    int accepted = 0;
+    for (int i = 0; i < n1; ++i) {
+        const float *f = desc1 + (size_t)i * ORACLE_DESC_LEN;
+        /* :1033-1035 */
+        int closest = -1;
+        int second = -1;
+        float minDist = -1.0f;
+        /* :1036-1047 */
+        for (int j = 0; j < n2; ++j) {
+            float dist = oracle_descriptor_distance(f, desc2 + (size_t)j * ORACLE_DESC_LEN);
+            if (minDist == -1.0f || dist < minDist) {
+                second = closest;
+                closest = j;
+                minDist = dist;
+            }
+        }
+        float secondDist = -1.0f;
+        if (second >= 0)
+            secondDist = oracle_descriptor_distance(f, desc2 + (size_t)second * ORACLE_DESC_LEN);
+
+        uint8_t status;
+        if (closest == -1 || second == -1 || closest == second) {
+            status = ORACLE_MATCH_FAILED; /* :1049-1054 */
+        } else if (fabsf(score1[i] - score2[closest]) > dist_limit) {
+            status = ORACLE_MATCH_SCORE; /* :1057-1060, float abs */
+        } else {
+            /* :1063-1067.  NN_RATIO is the double literal 0.8 (Features.h:33):
+             * the float ratio is promoted to double for the comparison. */
+            float ratio = minDist / secondDist;
+            if ((double)ratio < 0.8) {
+                status = ORACLE_MATCH_ACCEPTED;
+                ++accepted;
+            } else {
+                status = ORACLE_MATCH_RATIO;
+            }
+        }
+        if (closest_out) closest_out[i] = closest;
+        if (second_out) second_out[i] = second;
+        if (min_dist_out) min_dist_out[i] = minDist;
+        if (second_dist_out) second_dist_out[i] = secondDist;
+        if (status_out) status_out[i] = status;
+    }
+    return accepted;
+}
+
+/* ------------------------------------------------------------------ R --- */
+
+/* 2x2 minor used by the cofactor expansion: m(i1,j1)*m(i2,j2) - m(i1,j2)*m(i2,j1)
+ * with i1=(i+1)%3, i2=(i+2)%3 (Eigen's cofactor_3x3<i,j>). */
+static float cof3(const float m[9], int i, int j)
+{
+    int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+    int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    float p = m[i1 * 3 + j1] * m[i2 * 3 + j2];
+    float q = m[i1 * 3 + j2] * m[i2 * 3 + j1];
+    return p - q;
+}
+
+/* Eigen 3.3 compute_inverse<Matrix3f, 3>: first cofactor column, determinant
+ * as its dot product with column 0 reduced as a0 + (a1 + a2), one reciprocal,
+ * then every cofactor times that reciprocal.  Called at Stereography.cpp:617. */
+void oracle_invert3x3(const float H[9], float Hinv[9])
+{
+    float c00 = cof3(H, 0, 0), c10 = cof3(H, 1, 0), c20 = cof3(H, 2, 0);
+    float a0 = c00 * H[0], a1 = c10 * H[3], a2 = c20 * H[6];
+    float det = a0 + (a1 + a2);
+    float invdet = 1.0f / det;
+    /* result(j,i) = cofactor<i,j> * invdet */
+    Hinv[0] = c00 * invdet;
+    Hinv[1] = c10 * invdet;
+    Hinv[2] = c20 * invdet;
+    Hinv[3] = cof3(H, 0, 1) * invdet;
+    Hinv[4] = cof3(H, 1, 1) * invdet;
+    Hinv[5] = cof3(H, 2, 1) * invdet;
+    Hinv[6] = cof3(H, 0, 2) * invdet;
+    Hinv[7] = cof3(H, 1, 2) * invdet;
+    Hinv[8] = cof3(H, 2, 2) * invdet;
+}
+
+/* float -> uchar as the reference's x86-64 build performs it: truncate toward
+ * zero to a 32-bit int, keep the low byte; NaN gives 0 (cvttss2si returns
+ * 0x80000000).  Stated explicitly instead of relying on undefined behaviour. */
+static uint8_t to_uchar(float v)
+{
+    if (isnan(v)) return 0;
+    if (v >= 2147483648.0f || v < -2147483648.0f) return 0;
+    return (uint8_t)((int32_t)v & 0xFF);
+}
+
+/* Stereography.cpp:577-594 */
+uint8_t oracle_bilinear(const uint8_t *img, size_t stride, float x, float y)
+{
+    float x1 = floorf(x); /* :584 */
+    float x2 = ceilf(x);  /* :585 */
+    float y1 = floorf(y); /* :586 */
+    float y2 = ceilf(y);  /* :587 */
+    int ix1 = (int)x1, ix2 = (int)x2, iy1 = (int)y1, iy2 = (int)y2;
+    float wx1 = (x2 - x) / (x2 - x1); /* 0/0 = NaN when x is an integer */
+    float wx2 = (x - x1) / (x2 - x1);
+    /* :589-590, products and sum in float, then truncation to uchar */
+    uint8_t y1Val = to_uchar(wx1 * (float)img[(size_t)iy1 * stride + ix1] +
+                             wx2 * (float)img[(size_t)iy1 * stride + ix2]);
+    uint8_t y2Val = to_uchar(wx1 * (float)img[(size_t)iy2 * stride + ix1] +
+                             wx2 * (float)img[(size_t)iy2 * stride + ix2]);
+    float wy1 = (y2 - y) / (y2 - y1);
+    float wy2 = (y - y1) / (y2 - y1);
+    return to_uchar(wy1 * (float)y1Val + wy2 * (float)y2Val); /* :592 */
+}
+
+/* Stereography.cpp:612-630 */
+void oracle_rectify(const uint8_t *src, int src_w, int src_h, size_t src_stride,
+                    uint8_t *dst, int dst_w, int dst_h, size_t dst_stride,
+                    const float Hinv[9])
+{
+    float xmax = (float)(src_w - 1); /* original.cols - 1 promoted, :621 */
+    float ymax = (float)(src_h - 1); /* :623 */
+    for (int y = 0; y < dst_h; ++y) {
+        for (int x = 0; x < dst_w; ++x) {
+            float px = (float)x, py = (float)y; /* Vector3f pixel(x, y, 1), :616 */
+            /* :617 3x3 * 3x1: row dot product reduced as a0 + (a1 + a2) */
+            float q[3];
+            for (int i = 0; i < 3; ++i) {
+                float a0 = Hinv[i * 3 + 0] * px;
+                float a1 = Hinv[i * 3 + 1] * py;
+                float a2 = Hinv[i * 3 + 2] * 1.0f;
+                q[i] = a0 + (a1 + a2);
+            }
+            /* :618 true division by the saved third coordinate (Eigen >= 3.3) */
+            float z = q[2];
+            float tx = q[0] / z;
+            float ty = q[1] / z;
+            if (0.0f < tx && tx < xmax) {     /* :621 */
+                if (0.0f < ty && ty < ymax) { /* :623 */
+                    dst[(size_t)y * dst_stride + x] = oracle_bilinear(src, src_stride, tx, ty);
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ D --- */
+
+/* Stereography.cpp:664-688 */
+void oracle_disparity_ref(const uint8_t *img0, const uint8_t *img1, int w, int h,
+                          size_t stride, uint8_t *out, size_t out_stride)
+{
+    for (int y = 0; y < h; ++y) {
+        const uint8_t *r0 = img0 + (size_t)y * stride;
+        const uint8_t *r1 = img1 + (size_t)y * stride;
+        uint8_t *o = out + (size_t)y * out_stride;
+        for (int x = 0; x < w; ++x) {
+            int pixel0 = r0[x];
+            if (pixel0 == 0) { /* :670, depth stays Mat::zeros */
+                o[x] = 0;
+                continue;
+            }
+            int xBest = 0;      /* :671 */
+            int distance = 255; /* :672 */
+            for (int x1 = 0; x1 < w; ++x1) {
+                int pixel1 = r1[x1];
+                if (pixel1 == 0) continue; /* :676 */
+                int ad = abs(pixel1 - pixel0);
+                if (ad < distance) { /* :677 */
+                    distance = ad;
+                    xBest = x1;
+                }
+            }
+            o[x] = (uint8_t)(abs(xBest - x) & 0xFF); /* :686 int -> uchar */
+        }
+    }
+}
+
+static void store_out(void *out, size_t out_stride_bytes, int out_bytes, int y, int x, int v)
+{
+    uint8_t *row = (uint8_t *)out + (size_t)y * out_stride_bytes;
+    if (out_bytes == 1)
+        row[x] = (uint8_t)(v & 0xFF);
+    else
+        ((uint16_t *)row)[x] = (uint16_t)(v & 0xFFFF);
+}
+
+static int ext_args_ok(int w, int h, int win, int max_disp, int cost_mode, int out_bytes)
+{
+    if (w < 0 || h < 0) return 0;
+    if (win < 1 || (win & 1) == 0) return 0;
+    if (max_disp < 0) return 0;
+    if (cost_mode != 0 && cost_mode != 1) return 0;
+    if (out_bytes != 1 && out_bytes != 2) return 0;
+    return 1;
+}
+
+/* D1-ext, brute force.  Not in the reference. */
+int oracle_disparity_ext(const uint8_t *img0, const uint8_t *img1, int w, int h,
+                         size_t stride, int win, int max_disp, int cost_mode,
+                         void *out, size_t out_stride_bytes, int out_bytes)
+{
+    if (!ext_args_ok(w, h, win, max_disp, cost_mode, out_bytes)) return -1;
+    const int r = win / 2;
+    const long long init = (cost_mode ? 65025LL : 255LL) * win * win;
+    for (int y = 0; y < h; ++y) {
+        for (int x = 0; x < w; ++x) {
+            int p0 = img0[(size_t)y * stride + x];
+            if (p0 == 0) {
+                store_out(out, out_stride_bytes, out_bytes, y, x, 0);
+                continue;
+            }
+            int lo = 0, hi = w - 1;
+            if (max_disp > 0) {
+                lo = x - max_disp + 1;
+                if (lo < 0) lo = 0;
+                hi = x;
+            }
+            int xBest = 0;
+            long long best = init;
+            for (int x1 = lo; x1 <= hi; ++x1) {
+                if (img1[(size_t)y * stride + x1] == 0) continue;
+                long long cost = 0;
+                for (int dy = -r; dy <= r; ++dy) {
+                    int yy = y + dy;
+                    if (yy < 0 || yy >= h) continue;
+                    for (int dx = -r; dx <= r; ++dx) {
+                        int xa = x + dx, xb = x1 + dx;
+                        if (xa < 0 || xa >= w || xb < 0 || xb >= w) continue;
+                        int ad = abs((int)img1[(size_t)yy * stride + xb] -
+                                     (int)img0[(size_t)yy * stride + xa]);
+                        cost += cost_mode ? (long long)ad * ad : ad;
+                    }
+                }
+                if (cost < best) {
+                    best = cost;
+                    xBest = x1;
+                }
+            }
+            store_out(out, out_stride_bytes, out_bytes, y, x, abs(xBest - x));
+        }
+    }
+    return 0;
+}
+
+/* D1-ext with separable sliding sums: for each disparity d the per-pixel term
+ * T_d(y,x') (zero where x'-d < 0) is summed down columns, then along rows.
+ * Same result as the brute-force form; bounded mode only (or win == 1). */
+int oracle_disparity_ext_sliding(const uint8_t *img0, const uint8_t *img1, int w,
+                                 int h, size_t stride, int win, int max_disp,
+                                 int cost_mode, void *out, size_t out_stride_bytes,
+                                 int out_bytes)
+{
+    if (!ext_args_ok(w, h, win, max_disp, cost_mode, out_bytes)) return -1;
+    if (max_disp == 0) {
+        if (win != 1) return -1;
+        return oracle_disparity_ext(img0, img1, w, h, stride, win, max_disp, cost_mode,
+                                    out, out_stride_bytes, out_bytes);
+    }
+    if (w == 0 || h == 0) return 0;
+    const int r = win / 2;
+    const uint32_t init = (uint32_t)((cost_mode ? 65025u : 255u) * (uint32_t)win * (uint32_t)win);
+    uint32_t *best = (uint32_t *)malloc((size_t)w * h * sizeof(uint32_t));
+    int32_t *bestx = (int32_t *)malloc((size_t)w * h * sizeof(int32_t));
+    uint32_t *col = (uint32_t *)calloc((size_t)w, sizeof(uint32_t));
+    uint32_t *pre = (uint32_t *)malloc(((size_t)w + 1) * sizeof(uint32_t));
+    if (!best || !bestx || !col || !pre) {
+        free(best); free(bestx); free(col); free(pre);
+        return -1;
+    }
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+        best[i] = init;
+        bestx[i] = 0;
+    }
+    int dmax = max_disp < w ? max_disp : w;
+    /* ascending x1 == descending d; strict < keeps the earlier (lower x1) */
+    for (int d = dmax - 1; d >= 0; --d) {
+        memset(col, 0, (size_t)w * sizeof(uint32_t));
+        /* prime the column sums with rows [0, r) so that adding row y+r at
+         * step y gives rows [y-r, y+r] clipped to the image */
+        for (int yy = 0; yy < r && yy < h; ++yy)
+            for (int xx = d; xx < w; ++xx) {
+                int ad = abs((int)img1[(size_t)yy * stride + xx - d] - (int)img0[(size_t)yy * stride + xx]);
+                col[xx] += cost_mode ? (uint32_t)(ad * ad) : (uint32_t)ad;
+            }
+        for (int y = 0; y < h; ++y) {
+            int ya = y + r, ys = y - r - 1;
+            if (ya < h)
+                for (int xx = d; xx < w; ++xx) {
+                    int ad = abs((int)img1[(size_t)ya * stride + xx - d] - (int)img0[(size_t)ya * stride + xx]);
+                    col[xx] += cost_mode ? (uint32_t)(ad * ad) : (uint32_t)ad;
+                }
+            if (ys >= 0)
+                for (int xx = d; xx < w; ++xx) {
+                    int ad = abs((int)img1[(size_t)ys * stride + xx - d] - (int)img0[(size_t)ys * stride + xx]);
+                    col[xx] -= cost_mode ? (uint32_t)(ad * ad) : (uint32_t)ad;
+                }
+            pre[0] = 0;
+            for (int xx = 0; xx < w; ++xx) pre[xx + 1] = pre[xx] + col[xx];
+            const uint8_t *r0 = img0 + (size_t)y * stride;
+            const uint8_t *r1 = img1 + (size_t)y * stride;
+            for (int x = d; x < w; ++x) {
+                if (r0[x] == 0 || r1[x - d] == 0) continue;
+                int a = x - r, b = x + r + 1;
+                if (a < 0) a = 0;
+                if (b > w) b = w;
+                uint32_t cost = pre[b] - pre[a];
+                size_t idx = (size_t)y * w + x;
+                if (cost < best[idx]) {
+                    best[idx] = cost;
+                    bestx[idx] = x - d;
+                }
+            }
+        }
+    }
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            int v = 0;
+            if (img0[(size_t)y * stride + x] != 0) v = abs(bestx[(size_t)y * w + x] - x);
+            store_out(out, out_stride_bytes, out_bytes, y, x, v);
+        }
+    free(best); free(bestx); free(col); free(pre);
+    return 0;
+}

@@ -1,0 +1,97 @@
+/*
+ * stereo_oracle.h -- CPU restatement of the three hot-path functions of
+ * dmckinnon/stereo.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load or call anything in oracle/.  The product (libstereo_hip.so and the
+ * stereo_amd package) never links, imports or falls back to this code.
+ *
+ * PARITY UNPINNED: the reference ships no golden vectors or known-answer tests
+ * for this path and cannot be compiled in this image
+ * (it needs OpenCV 3.4.1, Eigen and <Windows.h>).  The pins are hand-derived
+ * known-answer cases in tests/test_oracle_kat.py that were worked out by
+ * reading the reference source, plus fixtures generated from this restatement
+ * (tests/golden/, generator tests/golden/make_golden.py).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile); the
+ * reference's working configuration is an unoptimised MSVC x64 build
+ * (stereo/stereo.vcxproj:87-105), i.e. no FMA contraction and no reassociation.
+ */
+#ifndef STEREO_ORACLE_H
+#define STEREO_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORACLE_DESC_LEN 128 /* DESC_LENGTH, stereo/Features.h:46 */
+
+/* per-query outcome codes written to status[] by oracle_match */
+#define ORACLE_MATCH_FAILED 0   /* "Error: failed to match feature i", Features.cpp:1049-1054 */
+#define ORACLE_MATCH_SCORE 1    /* rejected by the score gate, Features.cpp:1057-1060 */
+#define ORACLE_MATCH_RATIO 2    /* rejected by the ratio test, Features.cpp:1062-1067 */
+#define ORACLE_MATCH_ACCEPTED 3 /* pair pushed, Features.cpp:1069-1074 */
+
+/* DistanceBetweenDescriptors + L2_norm, stereo/Features.cpp:806-815, 1007-1018 */
+float oracle_descriptor_distance(const float *a, const float *b);
+
+/* MatchDescriptors, stereo/Features.cpp:1020-1079.  desc*: [n][128] row-major.
+ * Outputs are per query i of list1 (any may be NULL):
+ *   closest[i], second[i]  final values of closest / secondClosest (-1 = unset)
+ *   min_dist[i]            final minDist (-1.0f if list2 is empty)
+ *   second_dist[i]         distance to list2[second[i]] (-1.0f if second < 0)
+ *   status[i]              ORACLE_MATCH_* above
+ * Returns the number of accepted pairs. */
+int oracle_match(const float *desc1, const float *score1, int n1,
+                 const float *desc2, const float *score2, int n2,
+                 float dist_limit, int32_t *closest, int32_t *second,
+                 float *min_dist, float *second_dist, uint8_t *status);
+
+/* Eigen::Matrix3f::inverse() (cofactor / determinant form, fp32), as called at
+ * stereo/Stereography.cpp:617.  Row-major 3x3 in and out.  Third-party
+ * arithmetic restated from Eigen's published algorithm; version unpinned. */
+void oracle_invert3x3(const float H[9], float Hinv[9]);
+
+/* BilinearInterpolatePixel, stereo/Stereography.cpp:577-594 */
+uint8_t oracle_bilinear(const uint8_t *img, size_t stride, float x, float y);
+
+/* RectifyImage, stereo/Stereography.cpp:596-631, with H.inverse() hoisted and
+ * passed in as Hinv (row-major).  dst pixels that fail the bounds tests keep
+ * their prior contents. */
+void oracle_rectify(const uint8_t *src, int src_w, int src_h, size_t src_stride,
+                    uint8_t *dst, int dst_w, int dst_h, size_t dst_stride,
+                    const float Hinv[9]);
+
+/* ComputeDepthImage, stereo/Stereography.cpp:649-691 (reference mode: 1x1
+ * window, whole-row search, both directions).  out is w*h, fully written
+ * (zero where the reference leaves Mat::zeros untouched). */
+void oracle_disparity_ref(const uint8_t *img0, const uint8_t *img1, int w, int h,
+                          size_t stride, uint8_t *out, size_t out_stride);
+
+/* D1-ext: NOT in the reference; this repository's
+ * generalisation that collapses to oracle_disparity_ref for win=1,
+ * max_disp=0.  See DESIGN.md "D1-ext semantics".
+ *   win       odd window side >= 1
+ *   max_disp  D > 0: candidates x1 in [max(0, x-D+1), x]; 0: whole row
+ *   cost_mode 0 = SAD, 1 = SSD
+ *   out_bytes 1 = uint8 output (value mod 256), 2 = uint16 (value mod 65536)
+ * Returns 0, or -1 on invalid arguments. */
+int oracle_disparity_ext(const uint8_t *img0, const uint8_t *img1, int w, int h,
+                         size_t stride, int win, int max_disp, int cost_mode,
+                         void *out, size_t out_stride_bytes, int out_bytes);
+
+/* Same result as oracle_disparity_ext, computed with separable sliding sums
+ * (O(w*h*D) instead of O(w*h*D*win^2)); used for the cpu_baseline timing and
+ * cross-checked against the brute-force form in tests. */
+int oracle_disparity_ext_sliding(const uint8_t *img0, const uint8_t *img1, int w,
+                                 int h, size_t stride, int win, int max_disp,
+                                 int cost_mode, void *out, size_t out_stride_bytes,
+                                 int out_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

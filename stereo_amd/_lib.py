@@ -1,0 +1,90 @@
+"""ctypes binding of libstereo_hip.so (C ABI: include/stereo_hip.h).
+
+The library is the product; this module only declares its prototypes.  If the
+shared object is missing the loader raises -- there is no fallback path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class StereoHipError(RuntimeError):
+    """A libstereo_hip entry point returned a non-zero status."""
+
+    def __init__(self, code, where):
+        self.code = code
+        msg = "?"
+        try:
+            msg = load_library().stx_error_string(code).decode()
+        except Exception:  # pragma: no cover - only when the library is absent
+            pass
+        super().__init__("%s failed with status %d: %s" % (where, code, msg))
+
+
+def library_path():
+    return os.environ.get("STEREO_HIP_LIB", os.path.join(_HERE, "libstereo_hip.so"))
+
+
+# name -> (restype, argtypes); kept in one table so tests can check that every
+# symbol declared in include/stereo_hip.h is exported and bound.
+_u8p = C.POINTER(C.c_uint8)
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+PROTOTYPES = {
+    "stx_version": (C.c_int, []),
+    "stx_error_string": (C.c_char_p, [C.c_int]),
+    "stx_device_count": (C.c_int, []),
+    "stx_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "stx_destroy": (None, [_vp]),
+    "stx_set_stream": (C.c_int, [_vp, _vp]),
+    "stx_synchronize": (C.c_int, [_vp]),
+    "stx_set_match_algo": (C.c_int, [_vp, C.c_int]),
+    "stx_match": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_float,
+                            _vp, _vp, _vp, _vp, _vp]),
+    "stx_match_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_float,
+                                _vp, _vp, _vp, _vp, _vp]),
+    "stx_invert_homography": (C.c_int, [_f32p, _f32p]),
+    "stx_rectify_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_int,
+                                 C.c_int, C.c_size_t, _f32p, C.c_int]),
+    "stx_rectify_u8_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
+                                     _vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, _f32p,
+                                     C.c_int, C.c_int]),
+    "stx_disparity_u8": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_size_t, C.c_int,
+                                   C.c_int, C.c_int, _vp, C.c_size_t]),
+    "stx_disparity_u16": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_size_t, C.c_int,
+                                    C.c_int, C.c_int, _vp, C.c_size_t]),
+    "stx_disparity_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t,
+                                    C.c_size_t, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t,
+                                    C.c_size_t, C.c_int]),
+    "stx_disparity_rowband_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, _vp, C.c_size_t, C.c_int]),
+}
+
+
+def load_library():
+    """Load libstereo_hip.so once and attach prototypes.  Raises if it is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "libstereo_hip.so not found at %s -- build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C stereo_amd/csrc`.  stereo_amd has no CPU fallback." % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(code, where):
+    if code != 0:
+        raise StereoHipError(code, where)

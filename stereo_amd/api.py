@@ -1,0 +1,274 @@
+"""Host-side mirror of the reference's three hot-path functions.
+
+The reference is C++ (OpenCV Mat / Eigen in and out); its drop-in adapter is
+stereo_amd/adapter/stereo_dropin.hpp.  This module offers the same three
+operations, with the same names, argument meaning and error behaviour, on numpy
+arrays (and torch device tensors for the *_dev forms), so that tests and
+benchmarks can drive libstereo_hip.so through its C ABI.
+
+    MatchDescriptors(list1, list2, distLimitBetweenMatches)   Features.h:195-196
+    RectifyImage(original, rectified, H)                      Stereography.h:48-51
+    ComputeDepthImage(img0, img1)                             Stereography.h:53-55
+"""
+import copy
+import ctypes as C
+import os
+import sys
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+# stereo/Features.h:33-34
+NN_RATIO = 0.8
+MAX_DIST_BETWEEN_MATCHES = 1000.0
+DESC_LENGTH = 128
+
+MATCH_FAILED, MATCH_SCORE, MATCH_RATIO, MATCH_ACCEPTED = 0, 1, 2, 3
+COST_SAD, COST_SSD = 0, 1
+RECT_PRESERVE_DST, RECT_DST_IS_ZERO = 0, 1
+MATCH_AUTO, MATCH_EXACT, MATCH_MFMA = 0, 1, 2
+
+
+@dataclass
+class Feature:
+    """struct Feature, stereo/Features.h:52-84 (p is cv::Point2f as (x, y))."""
+    scale: int = 0
+    p: tuple = (0.0, 0.0)
+    score: float = 0.0
+    angle: float = 0.0
+    desc: np.ndarray = field(default_factory=lambda: np.zeros(DESC_LENGTH, np.float32))
+    distFromBestMatch: float = 0.0
+    depth: float = 0.0
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """One stx_ctx: bound to one HIP device and one stream."""
+
+    def __init__(self, device=None):
+        self._lib = _lib.load_library()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        h = C.c_void_p()
+        check(self._lib.stx_create(C.byref(h), int(device)), "stx_create")
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.stx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover - interpreter shutdown order
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing ---------------------------------------------------------
+    def set_stream(self, hip_stream):
+        """hip_stream: integer handle, e.g. torch.cuda.current_stream().cuda_stream."""
+        check(self._lib.stx_set_stream(self._h, C.c_void_p(int(hip_stream))), "stx_set_stream")
+
+    def synchronize(self):
+        check(self._lib.stx_synchronize(self._h), "stx_synchronize")
+
+    def set_match_algo(self, algo):
+        check(self._lib.stx_set_match_algo(self._h, int(algo)), "stx_set_match_algo")
+
+    # -- M ------------------------------------------------------------------
+    def match(self, desc1, score1, desc2, score2, dist_limit=MAX_DIST_BETWEEN_MATCHES):
+        """Arrays in, per-query arrays out: (closest, second, min_dist, second_dist, status)."""
+        desc1 = np.ascontiguousarray(desc1, np.float32).reshape(-1, DESC_LENGTH)
+        desc2 = np.ascontiguousarray(desc2, np.float32).reshape(-1, DESC_LENGTH)
+        score1 = np.ascontiguousarray(score1, np.float32).reshape(-1)
+        score2 = np.ascontiguousarray(score2, np.float32).reshape(-1)
+        n1, n2 = desc1.shape[0], desc2.shape[0]
+        if score1.shape[0] != n1 or score2.shape[0] != n2:
+            raise ValueError("score arrays must have one entry per descriptor")
+        closest = np.full(n1, -1, np.int32)
+        second = np.full(n1, -1, np.int32)
+        min_dist = np.full(n1, -1.0, np.float32)
+        second_dist = np.full(n1, -1.0, np.float32)
+        status = np.zeros(n1, np.uint8)
+        check(self._lib.stx_match(self._h, _ptr(desc1), _ptr(score1), n1, _ptr(desc2),
+                                  _ptr(score2), n2, C.c_float(dist_limit), _ptr(closest),
+                                  _ptr(second), _ptr(min_dist), _ptr(second_dist),
+                                  _ptr(status)), "stx_match")
+        return closest, second, min_dist, second_dist, status
+
+    def match_dev(self, desc1, score1, desc2, score2, dist_limit, closest, second, min_dist,
+                  second_dist, status):
+        """torch device tensors in and out; asynchronous on the context's stream."""
+        n1, n2 = int(desc1.shape[0]), int(desc2.shape[0])
+        check(self._lib.stx_match_dev(self._h, desc1.data_ptr(), score1.data_ptr(), n1,
+                                      desc2.data_ptr(), score2.data_ptr(), n2,
+                                      C.c_float(dist_limit), closest.data_ptr(),
+                                      second.data_ptr(), min_dist.data_ptr(),
+                                      second_dist.data_ptr(), status.data_ptr()), "stx_match_dev")
+
+    # -- R ------------------------------------------------------------------
+    def invert_homography(self, H):
+        H = np.ascontiguousarray(H, np.float32).reshape(9)
+        out = np.empty(9, np.float32)
+        fp = C.POINTER(C.c_float)
+        check(self._lib.stx_invert_homography(H.ctypes.data_as(fp), out.ctypes.data_as(fp)),
+              "stx_invert_homography")
+        return out.reshape(3, 3)
+
+    def rectify(self, original, rectified, Hinv, flags=RECT_PRESERVE_DST):
+        """original: HxW uint8; rectified: H'xW' uint8, modified in place."""
+        _check_image(original, "original")
+        _check_image(rectified, "rectified", writable=True)
+        Hinv = np.ascontiguousarray(Hinv, np.float32).reshape(9)
+        check(self._lib.stx_rectify_u8(
+            self._h, _ptr(original), original.shape[1], original.shape[0],
+            original.strides[0] if original.shape[0] > 1 else max(original.shape[1], 1),
+            _ptr(rectified), rectified.shape[1], rectified.shape[0],
+            rectified.strides[0] if rectified.shape[0] > 1 else max(rectified.shape[1], 1),
+            Hinv.ctypes.data_as(C.POINTER(C.c_float)), int(flags)), "stx_rectify_u8")
+        return rectified
+
+    def rectify_dev(self, src, dst, Hinv, flags=RECT_PRESERVE_DST):
+        """src: [n,H,W] or [H,W] uint8 device tensor; dst likewise; Hinv: n x 9 host floats."""
+        s3 = src if src.dim() == 3 else src.unsqueeze(0)
+        d3 = dst if dst.dim() == 3 else dst.unsqueeze(0)
+        n = int(s3.shape[0])
+        Hinv = np.ascontiguousarray(Hinv, np.float32).reshape(n, 9)
+        check(self._lib.stx_rectify_u8_dev(
+            self._h, s3.data_ptr(), int(s3.shape[2]), int(s3.shape[1]), int(s3.stride(1)),
+            int(s3.stride(0)), d3.data_ptr(), int(d3.shape[2]), int(d3.shape[1]),
+            int(d3.stride(1)), int(d3.stride(0)), Hinv.ctypes.data_as(C.POINTER(C.c_float)), n,
+            int(flags)), "stx_rectify_u8_dev")
+
+    # -- D ------------------------------------------------------------------
+    def disparity(self, img0, img1, win=1, max_disp=0, cost_mode=COST_SAD, out_dtype=np.uint8):
+        _check_image(img0, "img0")
+        _check_image(img1, "img1")
+        if img0.shape != img1.shape:
+            raise ValueError("img0 and img1 must have the same shape")
+        if img0.strides[0] != img1.strides[0] and img0.shape[0] > 1:
+            img1 = np.ascontiguousarray(img1)
+            img0 = np.ascontiguousarray(img0)
+        h, w = img0.shape
+        out_dtype = np.dtype(out_dtype)
+        out = np.zeros((h, w), out_dtype)
+        stride = img0.strides[0] if h > 1 else max(w, 1)
+        fn = {1: self._lib.stx_disparity_u8, 2: self._lib.stx_disparity_u16}[out_dtype.itemsize]
+        check(fn(self._h, _ptr(img0), _ptr(img1), w, h, stride, int(win), int(max_disp),
+                 int(cost_mode), _ptr(out), max(w, 1) * out_dtype.itemsize), "stx_disparity")
+        return out
+
+    def disparity_dev(self, img0, img1, out, win=1, max_disp=0, cost_mode=COST_SAD):
+        """img0/img1: [n,H,W] or [H,W] uint8 device tensors; out: same shape, uint8 or int16."""
+        a = img0 if img0.dim() == 3 else img0.unsqueeze(0)
+        b = img1 if img1.dim() == 3 else img1.unsqueeze(0)
+        o = out if out.dim() == 3 else out.unsqueeze(0)
+        if a.shape != b.shape or a.stride() != b.stride() or o.shape != a.shape:
+            raise ValueError("img0, img1 and out must agree in shape and layout")
+        n, h, w = (int(v) for v in a.shape)
+        ob = o.element_size()
+        check(self._lib.stx_disparity_dev(
+            self._h, a.data_ptr(), b.data_ptr(), n, w, h, int(a.stride(1)), int(a.stride(0)),
+            int(win), int(max_disp), int(cost_mode), o.data_ptr(), int(o.stride(1)) * ob,
+            int(o.stride(0)) * ob, ob), "stx_disparity_dev")
+
+    def disparity_rowband_dev(self, img0, img1, band_row0, full_h, row0, rows, out, win=1,
+                              max_disp=0, cost_mode=COST_SAD):
+        """img0/img1: [h_band, W] device tensors holding rows [band_row0, band_row0+h_band)."""
+        h, w = int(img0.shape[0]), int(img0.shape[1])
+        ob = out.element_size()
+        check(self._lib.stx_disparity_rowband_dev(
+            self._h, img0.data_ptr(), img1.data_ptr(), w, h, int(band_row0), int(full_h),
+            int(img0.stride(0)), int(row0), int(rows), int(win), int(max_disp), int(cost_mode),
+            out.data_ptr(), int(out.stride(0)) * ob, ob), "stx_disparity_rowband_dev")
+
+
+def _check_image(a, name, writable=False):
+    if not isinstance(a, np.ndarray) or a.dtype != np.uint8 or a.ndim != 2:
+        raise TypeError("%s must be a 2-D uint8 numpy array (CV_8U, one channel)" % name)
+    if a.shape[1] > 1 and a.strides[1] != 1:
+        raise ValueError("%s must have contiguous rows" % name)
+    if a.shape[0] > 1 and a.strides[0] < a.shape[1]:
+        raise ValueError("%s has overlapping rows" % name)
+    if writable and not a.flags.writeable:
+        raise ValueError("%s must be writable" % name)
+
+
+_DEFAULT = None
+
+
+def default_context():
+    global _DEFAULT
+    if _DEFAULT is None:
+        _DEFAULT = Context()
+    return _DEFAULT
+
+
+# --------------------------------------------------------------------------
+# The three reference signatures
+# --------------------------------------------------------------------------
+
+def MatchDescriptors(list1, list2, distLimitBetweenMatches, ctx=None, out=None):
+    """MatchDescriptors, stereo/Features.cpp:1020-1079.
+
+    list1/list2: sequences of Feature.  Returns a list of (Feature, Feature)
+    pairs -- copies, with distFromBestMatch set on both -- in ascending order of
+    the list1 index.  A query whose closest or second-closest is unset prints
+    the reference's line "Error: failed to match feature <i>" (:1052).
+    """
+    ctx = ctx or default_context()
+    out = out or sys.stdout
+    n1, n2 = len(list1), len(list2)
+    d1 = np.stack([np.asarray(f.desc, np.float32) for f in list1]) if n1 else np.zeros((0, 128), np.float32)
+    d2 = np.stack([np.asarray(f.desc, np.float32) for f in list2]) if n2 else np.zeros((0, 128), np.float32)
+    s1 = np.array([f.score for f in list1], np.float32)
+    s2 = np.array([f.score for f in list2], np.float32)
+    closest, second, min_dist, second_dist, status = ctx.match(d1, s1, d2, s2, distLimitBetweenMatches)
+    matches = []
+    for i in range(n1):
+        st = status[i]
+        if st == MATCH_FAILED:
+            out.write("Error: failed to match feature %d\n" % i)
+            continue
+        if st != MATCH_ACCEPTED:
+            continue
+        a = copy.deepcopy(list1[i])
+        b = copy.deepcopy(list2[int(closest[i])])
+        a.distFromBestMatch = float(min_dist[i])
+        b.distFromBestMatch = float(min_dist[i])
+        matches.append((a, b))
+    return matches
+
+
+def RectifyImage(original, rectified, H, ctx=None):
+    """RectifyImage, stereo/Stereography.cpp:596-631.
+
+    H is the forward homography (original -> rectified); it is inverted here
+    as the reference does at :617.  `rectified` is modified in place; pixels
+    whose source falls outside the strict bounds keep their prior value.
+    """
+    ctx = ctx or default_context()
+    Hinv = ctx.invert_homography(H)
+    ctx.rectify(original, rectified, Hinv, RECT_PRESERVE_DST)
+
+
+def ComputeDepthImage(img0, img1, ctx=None, out=None, win=1, max_disp=0, cost_mode=COST_SAD):
+    """ComputeDepthImage, stereo/Stereography.cpp:649-691.
+
+    With the default win=1, max_disp=0 this is the reference's scan.  A size
+    mismatch prints "Cannot compute depth!" and returns an empty 0x0 image
+    (:655-659).  win/max_disp/cost_mode select the D1-ext generalisation.
+    """
+    out = out or sys.stdout
+    if img0.shape[1] != img1.shape[1] or img0.shape[0] != img1.shape[0]:
+        out.write("Cannot compute depth!\n")
+        return np.zeros((0, 0), np.uint8)
+    ctx = ctx or default_context()
+    return ctx.disparity(img0, img1, win=win, max_disp=max_disp, cost_mode=cost_mode)

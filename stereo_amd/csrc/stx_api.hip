@@ -1,0 +1,372 @@
+// C-ABI entry points of libstereo_hip.so: context management and the host-pointer
+// forms, which stage through context-owned device buffers and call the kernel
+// launchers in disparity.hip / rectify.hip / match.hip.
+#include <new>
+#include <string.h>
+
+#include "stx_internal.h"
+
+extern "C" int stx_version(void) { return STX_VERSION; }
+
+extern "C" const char *stx_error_string(int code)
+{
+    switch (code) {
+    case STX_OK: return "ok";
+    case STX_ERR_INVALID_ARG: return "stereo_hip: invalid argument";
+    case STX_ERR_UNSUPPORTED: return "stereo_hip: unsupported parameter combination";
+    case STX_ERR_NO_DEVICE: return "stereo_hip: no such HIP device";
+    case STX_ERR_HOST_OOM: return "stereo_hip: host allocation failed";
+    case STX_ERR_TOO_LARGE: return "stereo_hip: problem size exceeds a kernel limit";
+    default: break;
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "stereo_hip: unknown error";
+}
+
+extern "C" int stx_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return -(int)e;
+    return n;
+}
+
+extern "C" int stx_create(stx_ctx **out, int device)
+{
+    if (!out) return STX_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return (int)e;
+    if (device < 0 || device >= n) return STX_ERR_NO_DEVICE;
+    STX_HIP(hipSetDevice(device));
+    stx_ctx *ctx = new (std::nothrow) stx_ctx();
+    if (!ctx) return STX_ERR_HOST_OOM;
+    memset(ctx, 0, sizeof(*ctx));
+    ctx->device = device;
+    ctx->stream = nullptr;
+    ctx->match_algo = STX_MATCH_AUTO;
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        delete ctx;
+        return (int)e;
+    }
+    ctx->num_cus = prop.multiProcessorCount;
+    *out = ctx;
+    return STX_OK;
+}
+
+extern "C" void stx_destroy(stx_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < STX_SLOT_COUNT; ++i)
+        if (ctx->slot_ptr[i]) (void)hipFree(ctx->slot_ptr[i]);
+    delete ctx;
+}
+
+extern "C" int stx_set_stream(stx_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return STX_ERR_INVALID_ARG;
+    ctx->stream = (hipStream_t)hip_stream;
+    return STX_OK;
+}
+
+extern "C" int stx_synchronize(stx_ctx *ctx)
+{
+    if (!ctx) return STX_ERR_INVALID_ARG;
+    STX_HIP(hipSetDevice(ctx->device));
+    STX_HIP(hipStreamSynchronize(ctx->stream));
+    return STX_OK;
+}
+
+extern "C" int stx_set_match_algo(stx_ctx *ctx, int algo)
+{
+    if (!ctx) return STX_ERR_INVALID_ARG;
+    if (algo != STX_MATCH_AUTO && algo != STX_MATCH_EXACT && algo != STX_MATCH_MFMA)
+        return STX_ERR_INVALID_ARG;
+    ctx->match_algo = algo;
+    return STX_OK;
+}
+
+void *stx_workspace(stx_ctx *ctx, int slot, size_t bytes, int *err)
+{
+    *err = STX_OK;
+    if (bytes == 0) bytes = 256;
+    if (ctx->slot_bytes[slot] >= bytes) return ctx->slot_ptr[slot];
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { *err = (int)e; return nullptr; }
+    if (ctx->slot_ptr[slot]) {
+        (void)hipFree(ctx->slot_ptr[slot]);
+        ctx->slot_ptr[slot] = nullptr;
+        ctx->slot_bytes[slot] = 0;
+    }
+    size_t want = (bytes + 4095) & ~(size_t)4095;
+    void *p = nullptr;
+    e = hipMalloc(&p, want);
+    if (e != hipSuccess) { *err = (int)e; return nullptr; }
+    ctx->slot_ptr[slot] = p;
+    ctx->slot_bytes[slot] = want;
+    return p;
+}
+
+// ---------------------------------------------------------------- M (host) --
+
+extern "C" int stx_match_dev(stx_ctx *ctx, const float *d_desc1, const float *d_score1,
+                             int n1, const float *d_desc2, const float *d_score2, int n2,
+                             float dist_limit, int32_t *d_closest, int32_t *d_second,
+                             float *d_min_dist, float *d_second_dist, uint8_t *d_status)
+{
+    if (!ctx || n1 < 0 || n2 < 0) return STX_ERR_INVALID_ARG;
+    if (n1 > 0 && (!d_desc1 || !d_score1)) return STX_ERR_INVALID_ARG;
+    if (n2 > 0 && (!d_desc2 || !d_score2)) return STX_ERR_INVALID_ARG;
+    STX_HIP(hipSetDevice(ctx->device));
+    if (n1 == 0) return STX_OK;
+    return stx_launch_match(ctx, d_desc1, d_score1, n1, d_desc2, d_score2, n2, dist_limit,
+                            d_closest, d_second, d_min_dist, d_second_dist, d_status);
+}
+
+extern "C" int stx_match(stx_ctx *ctx, const float *desc1, const float *score1, int n1,
+                         const float *desc2, const float *score2, int n2, float dist_limit,
+                         int32_t *closest, int32_t *second, float *min_dist,
+                         float *second_dist, uint8_t *status)
+{
+    if (!ctx || n1 < 0 || n2 < 0) return STX_ERR_INVALID_ARG;
+    if (n1 > 0 && (!desc1 || !score1)) return STX_ERR_INVALID_ARG;
+    if (n2 > 0 && (!desc2 || !score2)) return STX_ERR_INVALID_ARG;
+    STX_HIP(hipSetDevice(ctx->device));
+    if (n1 == 0) return STX_OK;
+    int err;
+    const size_t d1b = (size_t)n1 * STX_DESC_LEN * sizeof(float);
+    const size_t d2b = (size_t)n2 * STX_DESC_LEN * sizeof(float);
+    float *dd1 = (float *)stx_workspace(ctx, STX_SLOT_DESC1, d1b, &err);
+    if (!dd1) return err;
+    float *dd2 = (float *)stx_workspace(ctx, STX_SLOT_DESC2, d2b, &err);
+    if (!dd2) return err;
+    // small arrays: score1[n1] score2[n2] closest[n1] second[n1] mind[n1] secd[n1] status[n1]
+    const size_t n1a = ((size_t)n1 + 63) & ~(size_t)63, n2a = ((size_t)n2 + 63) & ~(size_t)63;
+    const size_t small_bytes = 4 * n1a + 4 * n2a + 4 * 4 * n1a + n1a;
+    char *sm = (char *)stx_workspace(ctx, STX_SLOT_SMALL, small_bytes, &err);
+    if (!sm) return err;
+    float *ds1 = (float *)sm;
+    float *ds2 = (float *)(sm + 4 * n1a);
+    int32_t *dcl = (int32_t *)(sm + 4 * n1a + 4 * n2a);
+    int32_t *dse = dcl + n1a;
+    float *dmd = (float *)(dse + n1a);
+    float *dsd = dmd + n1a;
+    uint8_t *dst = (uint8_t *)(dsd + n1a);
+    hipStream_t s = ctx->stream;
+    STX_HIP(hipMemcpyAsync(dd1, desc1, d1b, hipMemcpyHostToDevice, s));
+    if (n2 > 0) STX_HIP(hipMemcpyAsync(dd2, desc2, d2b, hipMemcpyHostToDevice, s));
+    STX_HIP(hipMemcpyAsync(ds1, score1, 4 * (size_t)n1, hipMemcpyHostToDevice, s));
+    if (n2 > 0) STX_HIP(hipMemcpyAsync(ds2, score2, 4 * (size_t)n2, hipMemcpyHostToDevice, s));
+    int rc = stx_launch_match(ctx, dd1, ds1, n1, dd2, ds2, n2, dist_limit, dcl, dse, dmd, dsd, dst);
+    if (rc != STX_OK) return rc;
+    if (closest) STX_HIP(hipMemcpyAsync(closest, dcl, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
+    if (second) STX_HIP(hipMemcpyAsync(second, dse, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
+    if (min_dist) STX_HIP(hipMemcpyAsync(min_dist, dmd, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
+    if (second_dist) STX_HIP(hipMemcpyAsync(second_dist, dsd, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
+    if (status) STX_HIP(hipMemcpyAsync(status, dst, (size_t)n1, hipMemcpyDeviceToHost, s));
+    STX_HIP(hipStreamSynchronize(s));
+    return STX_OK;
+}
+
+// ---------------------------------------------------------------- R (host) --
+
+// Eigen 3.3 compute_inverse<Matrix3f,3> operation order (third-party arithmetic
+// restated): cofactor<i,j> = m(i1,j1)*m(i2,j2) - m(i1,j2)*m(i2,j1),
+// det = c00*m00 + (c10*m10 + c20*m20), every entry = cofactor * (1/det).
+static inline float stx_cof3(const float *m, int i, int j)
+{
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    volatile float p = m[i1 * 3 + j1] * m[i2 * 3 + j2];
+    volatile float q = m[i1 * 3 + j2] * m[i2 * 3 + j1];
+    return p - q;
+}
+
+extern "C" int stx_invert_homography(const float H[9], float Hinv[9])
+{
+    if (!H || !Hinv) return STX_ERR_INVALID_ARG;
+    float c[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c[i][j] = stx_cof3(H, i, j);
+    volatile float a0 = c[0][0] * H[0], a1 = c[1][0] * H[3], a2 = c[2][0] * H[6];
+    volatile float t = a1 + a2;
+    const float det = a0 + t;
+    const float invdet = 1.0f / det;
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 3; ++k) Hinv[r * 3 + k] = c[k][r] * invdet;
+    return STX_OK;
+}
+
+static int check_image(const void *p, int w, int h, size_t stride)
+{
+    if (w < 0 || h < 0) return STX_ERR_INVALID_ARG;
+    if (w > 0 && h > 0 && (!p || stride < (size_t)w)) return STX_ERR_INVALID_ARG;
+    return STX_OK;
+}
+
+extern "C" int stx_rectify_u8_dev(stx_ctx *ctx, const uint8_t *d_src, int src_w, int src_h,
+                                  size_t src_stride, size_t src_image_stride, uint8_t *d_dst,
+                                  int dst_w, int dst_h, size_t dst_stride,
+                                  size_t dst_image_stride, const float *Hinv, int n_images,
+                                  int flags)
+{
+    if (!ctx || !Hinv || n_images < 0) return STX_ERR_INVALID_ARG;
+    if (flags != STX_RECT_PRESERVE_DST && flags != STX_RECT_DST_IS_ZERO) return STX_ERR_INVALID_ARG;
+    int rc = check_image(d_src, src_w, src_h, src_stride);
+    if (rc) return rc;
+    rc = check_image(d_dst, dst_w, dst_h, dst_stride);
+    if (rc) return rc;
+    STX_HIP(hipSetDevice(ctx->device));
+    if (n_images == 0 || dst_w == 0 || dst_h == 0) return STX_OK;
+    int err;
+    float *d_hinv = (float *)stx_workspace(ctx, STX_SLOT_HINV, sizeof(float) * 9 * (size_t)n_images, &err);
+    if (!d_hinv) return err;
+    // pageable source: the copy is staged by the runtime before this returns
+    STX_HIP(hipMemcpyAsync(d_hinv, Hinv, sizeof(float) * 9 * (size_t)n_images,
+                           hipMemcpyHostToDevice, ctx->stream));
+    return stx_launch_rectify(ctx, d_src, src_w, src_h, src_stride, src_image_stride, d_dst,
+                              dst_w, dst_h, dst_stride, dst_image_stride, d_hinv, n_images, flags);
+}
+
+extern "C" int stx_rectify_u8(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h,
+                              size_t src_stride, uint8_t *dst, int dst_w, int dst_h,
+                              size_t dst_stride, const float Hinv[9], int flags)
+{
+    if (!ctx || !Hinv) return STX_ERR_INVALID_ARG;
+    if (flags != STX_RECT_PRESERVE_DST && flags != STX_RECT_DST_IS_ZERO) return STX_ERR_INVALID_ARG;
+    int rc = check_image(src, src_w, src_h, src_stride);
+    if (rc) return rc;
+    rc = check_image(dst, dst_w, dst_h, dst_stride);
+    if (rc) return rc;
+    STX_HIP(hipSetDevice(ctx->device));
+    if (dst_w == 0 || dst_h == 0) return STX_OK;
+    int err;
+    hipStream_t s = ctx->stream;
+    // device copies are densely pitched to a multiple of 16 bytes
+    const size_t sp = ((size_t)src_w + 15) & ~(size_t)15, dp = ((size_t)dst_w + 15) & ~(size_t)15;
+    uint8_t *dsrc = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG0, sp * (size_t)(src_h > 0 ? src_h : 1), &err);
+    if (!dsrc) return err;
+    uint8_t *ddst = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG1, dp * (size_t)dst_h, &err);
+    if (!ddst) return err;
+    if (src_w > 0 && src_h > 0)
+        STX_HIP(hipMemcpy2DAsync(dsrc, sp, src, src_stride, (size_t)src_w, (size_t)src_h,
+                                 hipMemcpyHostToDevice, s));
+    if (flags == STX_RECT_PRESERVE_DST)
+        STX_HIP(hipMemcpy2DAsync(ddst, dp, dst, dst_stride, (size_t)dst_w, (size_t)dst_h,
+                                 hipMemcpyHostToDevice, s));
+    rc = stx_rectify_u8_dev(ctx, dsrc, src_w, src_h, sp, 0, ddst, dst_w, dst_h, dp, 0, Hinv, 1, flags);
+    if (rc) return rc;
+    STX_HIP(hipMemcpy2DAsync(dst, dst_stride, ddst, dp, (size_t)dst_w, (size_t)dst_h,
+                             hipMemcpyDeviceToHost, s));
+    STX_HIP(hipStreamSynchronize(s));
+    return STX_OK;
+}
+
+// ---------------------------------------------------------------- D (host) --
+
+static int check_disparity_args(int w, int h, size_t stride, int win, int max_disp,
+                                int cost_mode, int out_bytes, size_t out_stride)
+{
+    if (w < 0 || h < 0 || max_disp < 0) return STX_ERR_INVALID_ARG;
+    if (win < 1 || (win & 1) == 0) return STX_ERR_INVALID_ARG;
+    if (cost_mode != STX_COST_SAD && cost_mode != STX_COST_SSD) return STX_ERR_INVALID_ARG;
+    if (out_bytes != 1 && out_bytes != 2) return STX_ERR_INVALID_ARG;
+    if (stride < (size_t)w || out_stride < (size_t)w * (size_t)out_bytes) return STX_ERR_INVALID_ARG;
+    if (out_bytes == 2 && (out_stride & 1)) return STX_ERR_INVALID_ARG;
+    if (max_disp == 0 && win != 1) return STX_ERR_UNSUPPORTED;
+    if (win > 31) return STX_ERR_UNSUPPORTED;
+    return STX_OK;
+}
+
+extern "C" int stx_disparity_rowband_dev(stx_ctx *ctx, const uint8_t *d_img0,
+                                         const uint8_t *d_img1, int w, int h, int band_row0,
+                                         int full_h, size_t stride, int row0, int rows,
+                                         int win, int max_disp, int cost_mode, void *d_out,
+                                         size_t out_stride, int out_bytes)
+{
+    if (!ctx) return STX_ERR_INVALID_ARG;
+    int rc = check_disparity_args(w, h, stride, win, max_disp, cost_mode, out_bytes, out_stride);
+    if (rc) return rc;
+    if (band_row0 < 0 || full_h < 0 || rows < 0 || row0 < band_row0 ||
+        band_row0 + h > full_h || row0 + rows > band_row0 + h)
+        return STX_ERR_INVALID_ARG;
+    // the band must carry the halo rows the full image has
+    const int r = win / 2;
+    const int need_lo = row0 - r > 0 ? row0 - r : 0;
+    const int need_hi = row0 + rows + r < full_h ? row0 + rows + r : full_h;
+    if (rows > 0 && (band_row0 > need_lo || band_row0 + h < need_hi)) return STX_ERR_INVALID_ARG;
+    if (w == 0 || rows == 0) return STX_OK;
+    if (!d_img0 || !d_img1 || !d_out) return STX_ERR_INVALID_ARG;
+    STX_HIP(hipSetDevice(ctx->device));
+    // A band whose first/last rows are interior rows of the full image has its
+    // window clipped only where the halo is present, so clipping against the
+    // band equals clipping against the full image.
+    return stx_launch_disparity(ctx, d_img0, d_img1, 1, w, h, stride, 0, row0 - band_row0, rows,
+                                win, max_disp, cost_mode, d_out, out_stride, 0, out_bytes);
+}
+
+extern "C" int stx_disparity_dev(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_img1,
+                                 int n_pairs, int w, int h, size_t stride, size_t pair_stride,
+                                 int win, int max_disp, int cost_mode, void *d_out,
+                                 size_t out_stride, size_t out_pair_stride, int out_bytes)
+{
+    if (!ctx || n_pairs < 0) return STX_ERR_INVALID_ARG;
+    int rc = check_disparity_args(w, h, stride, win, max_disp, cost_mode, out_bytes, out_stride);
+    if (rc) return rc;
+    if (n_pairs == 0 || w == 0 || h == 0) return STX_OK;
+    if (!d_img0 || !d_img1 || !d_out) return STX_ERR_INVALID_ARG;
+    if (n_pairs > 1 && (pair_stride < stride * (size_t)h || out_pair_stride < out_stride * (size_t)h))
+        return STX_ERR_INVALID_ARG;
+    STX_HIP(hipSetDevice(ctx->device));
+    return stx_launch_disparity(ctx, d_img0, d_img1, n_pairs, w, h, stride, pair_stride, 0, h, win,
+                                max_disp, cost_mode, d_out, out_stride, out_pair_stride, out_bytes);
+}
+
+static int disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int w, int h,
+                          size_t stride, int win, int max_disp, int cost_mode, void *out,
+                          size_t out_stride, int out_bytes)
+{
+    if (!ctx) return STX_ERR_INVALID_ARG;
+    int rc = check_disparity_args(w, h, stride, win, max_disp, cost_mode, out_bytes, out_stride);
+    if (rc) return rc;
+    if (w == 0 || h == 0) return STX_OK;
+    if (!img0 || !img1 || !out) return STX_ERR_INVALID_ARG;
+    STX_HIP(hipSetDevice(ctx->device));
+    int err;
+    hipStream_t s = ctx->stream;
+    const size_t p = ((size_t)w + 15) & ~(size_t)15;
+    const size_t op = p * (size_t)out_bytes;
+    uint8_t *d0 = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG0, p * (size_t)h, &err);
+    if (!d0) return err;
+    uint8_t *d1 = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG1, p * (size_t)h, &err);
+    if (!d1) return err;
+    uint8_t *dout = (uint8_t *)stx_workspace(ctx, STX_SLOT_OUT, op * (size_t)h, &err);
+    if (!dout) return err;
+    STX_HIP(hipMemcpy2DAsync(d0, p, img0, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, s));
+    STX_HIP(hipMemcpy2DAsync(d1, p, img1, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, s));
+    rc = stx_launch_disparity(ctx, d0, d1, 1, w, h, p, 0, 0, h, win, max_disp, cost_mode, dout, op, 0,
+                              out_bytes);
+    if (rc) return rc;
+    STX_HIP(hipMemcpy2DAsync(out, out_stride, dout, op, (size_t)w * (size_t)out_bytes, (size_t)h,
+                             hipMemcpyDeviceToHost, s));
+    STX_HIP(hipStreamSynchronize(s));
+    return STX_OK;
+}
+
+extern "C" int stx_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int w,
+                                int h, size_t stride, int win, int max_disp, int cost_mode,
+                                uint8_t *out, size_t out_stride)
+{
+    return disparity_host(ctx, img0, img1, w, h, stride, win, max_disp, cost_mode, out, out_stride, 1);
+}
+
+extern "C" int stx_disparity_u16(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int w,
+                                 int h, size_t stride, int win, int max_disp, int cost_mode,
+                                 uint16_t *out, size_t out_stride)
+{
+    return disparity_host(ctx, img0, img1, w, h, stride, win, max_disp, cost_mode, out, out_stride, 2);
+}

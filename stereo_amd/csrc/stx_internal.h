@@ -1,0 +1,60 @@
+// Internal declarations shared by the translation units of libstereo_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/stereo_hip.h"
+
+// Grow-only device workspace slots owned by a context.
+enum stx_slot {
+    STX_SLOT_IMG0 = 0,   // host-API staging: first input image(s)
+    STX_SLOT_IMG1,       // host-API staging: second input image / rectify dst
+    STX_SLOT_OUT,        // host-API staging: output
+    STX_SLOT_DESC1,      // host-API staging: list1 descriptors
+    STX_SLOT_DESC2,      // host-API staging: list2 descriptors
+    STX_SLOT_SMALL,      // host-API staging: scores + per-query outputs
+    STX_SLOT_HINV,       // rectify: per-image inverse homographies
+    STX_SLOT_M_FRAG,     // match: list2 in MFMA fragment order + norms
+    STX_SLOT_M_QNORM,    // match: query norms
+    STX_SLOT_M_CAND,     // match: candidate lists + counters
+    STX_SLOT_M_FALLBACK, // match: overflow query list
+    STX_SLOT_COUNT
+};
+
+struct stx_ctx {
+    int device;
+    hipStream_t stream;
+    int match_algo;
+    int num_cus;
+    void *slot_ptr[STX_SLOT_COUNT];
+    size_t slot_bytes[STX_SLOT_COUNT];
+};
+
+// Returns a device buffer of at least `bytes` bytes for `slot` (grow-only;
+// growing synchronises the stream, frees and reallocates).  nullptr + *err on failure.
+void *stx_workspace(stx_ctx *ctx, int slot, size_t bytes, int *err);
+
+#define STX_HIP(call)                                   \
+    do {                                                \
+        hipError_t stx_e_ = (call);                     \
+        if (stx_e_ != hipSuccess) return (int)stx_e_;   \
+    } while (0)
+
+// Kernel launchers (device pointers, asynchronous on ctx->stream).
+int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_img1,
+                         int n_pairs, int w, int h, size_t stride, size_t pair_stride,
+                         int row0, int rows, int win, int max_disp, int cost_mode,
+                         void *d_out, size_t out_stride, size_t out_pair_stride,
+                         int out_bytes);
+
+int stx_launch_rectify(stx_ctx *ctx, const uint8_t *d_src, int src_w, int src_h,
+                       size_t src_stride, size_t src_image_stride, uint8_t *d_dst,
+                       int dst_w, int dst_h, size_t dst_stride, size_t dst_image_stride,
+                       const float *d_hinv, int n_images, int flags);
+
+int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, int n1,
+                     const float *d_desc2, const float *d_score2, int n2,
+                     float dist_limit, int32_t *d_closest, int32_t *d_second,
+                     float *d_min_dist, float *d_second_dist, uint8_t *d_status);

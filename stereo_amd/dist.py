@@ -1,0 +1,90 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+
+Nothing on this path is a reduction.  Batches shard by whole image pairs,
+a single large pair shards by epipolar row bands (the disparity search is
+row-local; a win x win window needs win//2 halo rows, which each rank reads
+from its own copy of the input, so there is no GPU<->GPU halo exchange), and
+matching shards list1's queries with list2 replicated.  The only collective is
+the optional gather of results to rank 0.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, rank, world):
+    """Contiguous, balanced [lo, hi) share of n units for `rank`."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def row_band(full_h, rank, world, halo):
+    """Rows this rank outputs, and the rows it must hold to do so.
+
+    Returns (row0, rows, band_row0, band_rows): output rows [row0, row0+rows),
+    input rows [band_row0, band_row0+band_rows) = the output rows plus `halo`
+    rows on each side, clipped to the image."""
+    row0, row1 = shard_range(full_h, rank, world)
+    b0 = max(0, row0 - halo)
+    b1 = min(full_h, row1 + halo)
+    if row1 == row0:
+        b0, b1 = row0, row0
+    return row0, row1 - row0, b0, b1 - b0
+
+
+def gather_rows(local, counts, dst=0, group=None):
+    """Gather per-rank row blocks (dim 0, sizes `counts`) to rank `dst`.
+
+    Point-to-point sends into the root (grouped isend/irecv): on an 8-GPU
+    xGMI node that is 7 concurrent links into the root.  Returns the
+    concatenated tensor on `dst`, None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return local
+    if rank == dst:
+        parts = []
+        reqs = []
+        for r in range(world):
+            if r == dst:
+                parts.append(local)
+                continue
+            buf = torch.empty((counts[r],) + tuple(local.shape[1:]), dtype=local.dtype,
+                              device=local.device)
+            parts.append(buf)
+            if counts[r] > 0:
+                reqs.append(dist.irecv(buf, src=r, group=group))
+        for q in reqs:
+            q.wait()
+        return torch.cat(parts, dim=0)
+    if local.shape[0] > 0:
+        dist.isend(local.contiguous(), dst=dst, group=group).wait()
+    return None
+
+
+def disparity_rowbands(compute_band, img0, img1, win, group=None, gather=True):
+    """Row-band sharded disparity of ONE pair held (replicated) by every rank.
+
+    compute_band(img0_band, img1_band, band_row0, full_h, row0, rows) -> [rows, W]
+    tensor for output rows [row0, row0+rows).  Returns the full map on rank 0
+    (None elsewhere) when gather=True, else this rank's band."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    full_h = int(img0.shape[0])
+    row0, rows, b0, bh = row_band(full_h, rank, world, win // 2)
+    out = compute_band(img0[b0:b0 + bh], img1[b0:b0 + bh], b0, full_h, row0, rows)
+    if not gather or world == 1:
+        return out
+    counts = [row_band(full_h, r, world, win // 2)[1] for r in range(world)]
+    return gather_rows(out, counts, 0, group)
+
+
+def disparity_pairs(compute_pairs, n_pairs, group=None):
+    """Pair-sharded batch: rank r computes pairs shard_range(n_pairs, r, world).
+    compute_pairs(lo, hi) -> [hi-lo, H, W] tensor.  No collective: each rank
+    keeps (or copies out) its own results."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_range(n_pairs, rank, world)
+    return lo, hi, compute_pairs(lo, hi)

