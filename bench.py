@@ -29,7 +29,10 @@ sys.path.insert(0, ROOT)
 # MI355X constants (/opt/skills/guides/MI355X_MICROARCH.md)
 CUS = 256
 CLOCK_HZ = 2.4e9
-VALU_LANEOPS = CUS * 4 * 32 * CLOCK_HZ      # 4 SIMD-32 per CU, one lane-op per lane per clock
+# Integer VALU roofline: 256 CU x 64 lanes/clk x 2.4 GHz = 3.93e13 lane-ops/s.
+# tools/ubench.hip measures 3.5e13 (3-operand integer ops such as v_sad_u32 / v_min3_u32,
+# 8 waves per SIMD, clock throttled to ~1.5 GHz under that load) to 5.2e13 (v_add_u32).
+VALU_LANEOPS = CUS * 64 * CLOCK_HZ
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_TFLOPS = 157.3
 
@@ -154,8 +157,8 @@ def main():
         "unit": "Tlane-op/s",
         "frac": achieved / VALU_LANEOPS,
         "traffic": None,
-        "model": "%d integer lane-ops per (pixel,candidate) unit (SURVEY 8d); peak = %d CU x 4 SIMD x 32 "
-                 "lanes x %.1f GHz" % (OPS_PER_UNIT_WINDOWED, CUS, CLOCK_HZ / 1e9),
+        "model": "%d integer lane-ops per (pixel,candidate) unit (SURVEY 8d); peak = %d CU x 64 lanes/clk "
+                 "x %.1f GHz" % (OPS_PER_UNIT_WINDOWED, CUS, CLOCK_HZ / 1e9),
         "kernel_ms": kernel_ms,
         "hbm_GBps_algorithmic": 3.0 * W * H / (kernel_ms * 1e-3) / 1e9,
     }

@@ -65,6 +65,10 @@ extern "C" {
 #define STX_MATCH_EXACT 1 /* VALU scan in reference operation order */
 #define STX_MATCH_MFMA 2  /* fp32 MFMA prefilter + exact replay of the running-minimum records */
 
+/* disparity kernel selector (stx_set_disparity_algo) */
+#define STX_DISP_AUTO 0       /* sliding-sum kernel where it applies (SAD, win <= 9), else tap-by-tap */
+#define STX_DISP_BRUTEFORCE 1 /* tap-by-tap kernel for every D1-ext call */
+
 typedef struct stx_ctx stx_ctx;
 
 /* ---- library / context ------------------------------------------------- */
@@ -88,6 +92,10 @@ int stx_synchronize(stx_ctx *ctx);
 /* Choose the matching algorithm (STX_MATCH_*).  All algorithms give identical
  * outputs; this exists for testing and benchmarking. */
 int stx_set_match_algo(stx_ctx *ctx, int algo);
+
+/* Choose the D1-ext disparity kernel (STX_DISP_*).  Both give identical
+ * outputs; this exists for testing and benchmarking. */
+int stx_set_disparity_algo(stx_ctx *ctx, int algo);
 
 /* ---- M: descriptor matching --------------------------------------------
  * Replaces MatchDescriptors (Features.h:195-196).  desc1/desc2 are [n][128]
@@ -140,9 +148,11 @@ int stx_rectify_u8_dev(stx_ctx *ctx, const uint8_t *d_src, int src_w, int src_h,
  * first minimum wins, output |xBest - x| mod 256 (Stereography.cpp:664-688).
  *
  * win > 1 or max_disp > 0 select this library's generalisation (D1-ext,
- * DESIGN.md): odd win x win SAD/SSD window with out-of-image taps excluded,
+ * DESIGN.md): odd win x win SAD/SSD window,
  * candidates x1 in [max(0, x-max_disp+1), x] scanned in ascending x1, initial
  * best 255*win^2 (65025*win^2 for SSD), strict <.  max_disp = 0 requires win = 1.
+ * Both images are zero-extended outside their borders (a window tap that falls
+ * outside an image reads 0).
  * The reference's size-mismatch branch (Stereography.cpp:655-659) is handled
  * by the adapter, which owns both Mats. */
 int stx_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int w,

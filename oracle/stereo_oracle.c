@@ -257,12 +257,13 @@ int oracle_disparity_ext(const uint8_t *img0, const uint8_t *img1, int w, int h,
                 long long cost = 0;
                 for (int dy = -r; dy <= r; ++dy) {
                     int yy = y + dy;
-                    if (yy < 0 || yy >= h) continue;
+                    if (yy < 0 || yy >= h) continue; /* both taps read 0 */
                     for (int dx = -r; dx <= r; ++dx) {
                         int xa = x + dx, xb = x1 + dx;
-                        if (xa < 0 || xa >= w || xb < 0 || xb >= w) continue;
-                        int ad = abs((int)img1[(size_t)yy * stride + xb] -
-                                     (int)img0[(size_t)yy * stride + xa]);
+                        /* both images are zero-extended outside their borders */
+                        int a = (xa >= 0 && xa < w) ? img0[(size_t)yy * stride + xa] : 0;
+                        int b = (xb >= 0 && xb < w) ? img1[(size_t)yy * stride + xb] : 0;
+                        int ad = abs(b - a);
                         cost += cost_mode ? (long long)ad * ad : ad;
                     }
                 }
@@ -278,8 +279,9 @@ int oracle_disparity_ext(const uint8_t *img0, const uint8_t *img1, int w, int h,
 }
 
 /* D1-ext with separable sliding sums: for each disparity d the per-pixel term
- * T_d(y,x') (zero where x'-d < 0) is summed down columns, then along rows.
- * Same result as the brute-force form; bounded mode only (or win == 1). */
+ * T_d(y,x') = f(|img1z(y,x'-d) - img0z(y,x')|) (z = zero-extended) is summed
+ * down columns, then along rows.  Same result as the brute-force form; bounded
+ * mode only (or win == 1). */
 int oracle_disparity_ext_sliding(const uint8_t *img0, const uint8_t *img1, int w,
                                  int h, size_t stride, int win, int max_disp,
                                  int cost_mode, void *out, size_t out_stride_bytes,
@@ -294,10 +296,12 @@ int oracle_disparity_ext_sliding(const uint8_t *img0, const uint8_t *img1, int w
     if (w == 0 || h == 0) return 0;
     const int r = win / 2;
     const uint32_t init = (uint32_t)((cost_mode ? 65025u : 255u) * (uint32_t)win * (uint32_t)win);
+    /* extended column index e = x' + r + dmaxpad covers x' in [-r, w + r) */
+    const int ew = w + 2 * r;
     uint32_t *best = (uint32_t *)malloc((size_t)w * h * sizeof(uint32_t));
     int32_t *bestx = (int32_t *)malloc((size_t)w * h * sizeof(int32_t));
-    uint32_t *col = (uint32_t *)calloc((size_t)w, sizeof(uint32_t));
-    uint32_t *pre = (uint32_t *)malloc(((size_t)w + 1) * sizeof(uint32_t));
+    uint32_t *col = (uint32_t *)calloc((size_t)ew, sizeof(uint32_t));
+    uint32_t *pre = (uint32_t *)malloc(((size_t)ew + 1) * sizeof(uint32_t));
     if (!best || !bestx || !col || !pre) {
         free(best); free(bestx); free(col); free(pre);
         return -1;
@@ -307,38 +311,42 @@ int oracle_disparity_ext_sliding(const uint8_t *img0, const uint8_t *img1, int w
         bestx[i] = 0;
     }
     int dmax = max_disp < w ? max_disp : w;
+#define TERM(yy, xp)                                                                        \
+    do {                                                                                    \
+        int a_ = ((xp) >= 0 && (xp) < w) ? img0[(size_t)(yy) * stride + (xp)] : 0;          \
+        int b_ = ((xp) - d >= 0 && (xp) - d < w) ? img1[(size_t)(yy) * stride + (xp) - d] : 0; \
+        int ad_ = abs(b_ - a_);                                                             \
+        term = cost_mode ? (uint32_t)(ad_ * ad_) : (uint32_t)ad_;                           \
+    } while (0)
     /* ascending x1 == descending d; strict < keeps the earlier (lower x1) */
     for (int d = dmax - 1; d >= 0; --d) {
-        memset(col, 0, (size_t)w * sizeof(uint32_t));
-        /* prime the column sums with rows [0, r) so that adding row y+r at
-         * step y gives rows [y-r, y+r] clipped to the image */
+        uint32_t term;
+        memset(col, 0, (size_t)ew * sizeof(uint32_t));
         for (int yy = 0; yy < r && yy < h; ++yy)
-            for (int xx = d; xx < w; ++xx) {
-                int ad = abs((int)img1[(size_t)yy * stride + xx - d] - (int)img0[(size_t)yy * stride + xx]);
-                col[xx] += cost_mode ? (uint32_t)(ad * ad) : (uint32_t)ad;
+            for (int e = 0; e < ew; ++e) {
+                TERM(yy, e - r);
+                col[e] += term;
             }
         for (int y = 0; y < h; ++y) {
             int ya = y + r, ys = y - r - 1;
             if (ya < h)
-                for (int xx = d; xx < w; ++xx) {
-                    int ad = abs((int)img1[(size_t)ya * stride + xx - d] - (int)img0[(size_t)ya * stride + xx]);
-                    col[xx] += cost_mode ? (uint32_t)(ad * ad) : (uint32_t)ad;
+                for (int e = 0; e < ew; ++e) {
+                    TERM(ya, e - r);
+                    col[e] += term;
                 }
             if (ys >= 0)
-                for (int xx = d; xx < w; ++xx) {
-                    int ad = abs((int)img1[(size_t)ys * stride + xx - d] - (int)img0[(size_t)ys * stride + xx]);
-                    col[xx] -= cost_mode ? (uint32_t)(ad * ad) : (uint32_t)ad;
+                for (int e = 0; e < ew; ++e) {
+                    TERM(ys, e - r);
+                    col[e] -= term;
                 }
             pre[0] = 0;
-            for (int xx = 0; xx < w; ++xx) pre[xx + 1] = pre[xx] + col[xx];
+            for (int e = 0; e < ew; ++e) pre[e + 1] = pre[e] + col[e];
             const uint8_t *r0 = img0 + (size_t)y * stride;
             const uint8_t *r1 = img1 + (size_t)y * stride;
             for (int x = d; x < w; ++x) {
                 if (r0[x] == 0 || r1[x - d] == 0) continue;
-                int a = x - r, b = x + r + 1;
-                if (a < 0) a = 0;
-                if (b > w) b = w;
-                uint32_t cost = pre[b] - pre[a];
+                /* window columns x-r..x+r -> e = x .. x+2r */
+                uint32_t cost = pre[x + 2 * r + 1] - pre[x];
                 size_t idx = (size_t)y * w + x;
                 if (cost < best[idx]) {
                     best[idx] = cost;
@@ -347,6 +355,7 @@ int oracle_disparity_ext_sliding(const uint8_t *img0, const uint8_t *img1, int w
             }
         }
     }
+#undef TERM
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
             int v = 0;

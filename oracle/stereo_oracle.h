@@ -74,7 +74,8 @@ void oracle_disparity_ref(const uint8_t *img0, const uint8_t *img1, int w, int h
 /* D1-ext: NOT in the reference; this repository's
  * generalisation that collapses to oracle_disparity_ref for win=1,
  * max_disp=0.  See DESIGN.md "D1-ext semantics".
- *   win       odd window side >= 1
+ *   win       odd window side >= 1; both images are zero-extended outside
+ *             their borders (a tap that falls outside an image reads 0)
  *   max_disp  D > 0: candidates x1 in [max(0, x-D+1), x]; 0: whole row
  *   cost_mode 0 = SAD, 1 = SSD
  *   out_bytes 1 = uint8 output (value mod 256), 2 = uint16 (value mod 65536)

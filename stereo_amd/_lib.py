@@ -42,6 +42,7 @@ PROTOTYPES = {
     "stx_set_stream": (C.c_int, [_vp, _vp]),
     "stx_synchronize": (C.c_int, [_vp]),
     "stx_set_match_algo": (C.c_int, [_vp, C.c_int]),
+    "stx_set_disparity_algo": (C.c_int, [_vp, C.c_int]),
     "stx_match": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_float,
                             _vp, _vp, _vp, _vp, _vp]),
     "stx_match_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_float,

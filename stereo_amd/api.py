@@ -30,6 +30,7 @@ MATCH_FAILED, MATCH_SCORE, MATCH_RATIO, MATCH_ACCEPTED = 0, 1, 2, 3
 COST_SAD, COST_SSD = 0, 1
 RECT_PRESERVE_DST, RECT_DST_IS_ZERO = 0, 1
 MATCH_AUTO, MATCH_EXACT, MATCH_MFMA = 0, 1, 2
+DISP_AUTO, DISP_BRUTEFORCE = 0, 1
 
 
 @dataclass
@@ -81,6 +82,9 @@ class Context:
 
     def set_match_algo(self, algo):
         check(self._lib.stx_set_match_algo(self._h, int(algo)), "stx_set_match_algo")
+
+    def set_disparity_algo(self, algo):
+        check(self._lib.stx_set_disparity_algo(self._h, int(algo)), "stx_set_disparity_algo")
 
     # -- M ------------------------------------------------------------------
     def match(self, desc1, score1, desc2, score2, dist_limit=MAX_DIST_BETWEEN_MATCHES):
@@ -193,6 +197,8 @@ class Context:
 def _check_image(a, name, writable=False):
     if not isinstance(a, np.ndarray) or a.dtype != np.uint8 or a.ndim != 2:
         raise TypeError("%s must be a 2-D uint8 numpy array (CV_8U, one channel)" % name)
+    if a.size == 0:
+        return
     if a.shape[1] > 1 and a.strides[1] != 1:
         raise ValueError("%s must have contiguous rows" % name)
     if a.shape[0] > 1 and a.strides[0] < a.shape[1]:

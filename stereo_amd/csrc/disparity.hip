@@ -140,7 +140,7 @@ __global__ __launch_bounds__(EXT_THREADS) void disp_ext_bruteforce_kernel(
     const int x0 = blockIdx.x * EXT_TX;
     const int y0 = row0 + blockIdx.y * EXT_TY;
 
-    // stage tiles; out-of-image positions are zero-filled and never used as taps
+    // stage tiles; both images are zero-extended outside their borders
     for (int i = threadIdx.x; i < lw * th; i += EXT_THREADS) {
         const int ty = i / lw, tx = i - ty * lw;
         const int gy = y0 - r + ty, gx = x0 - r + tx;
@@ -158,7 +158,6 @@ __global__ __launch_bounds__(EXT_THREADS) void disp_ext_bruteforce_kernel(
     if (x >= w) return;
     const int win = 2 * r + 1;
     const unsigned init = (SSD ? 65025u : 255u) * (unsigned)win * (unsigned)win;
-    const int dx_hi = min(r, w - 1 - x);
 
     for (int ly = threadIdx.x / EXT_TX; ly < EXT_TY; ly += EXT_THREADS / EXT_TX) {
         const int y = y0 + ly;
@@ -166,7 +165,6 @@ __global__ __launch_bounds__(EXT_THREADS) void disp_ext_bruteforce_kernel(
         int v = 0;
         const unsigned p0 = Lt[(ly + r) * lw + lx + r];
         if (p0 != 0) {
-            const int dy_lo = max(-r, -y), dy_hi = min(r, h - 1 - y);
             unsigned best = init;
             int xbest = 0;
             const int dmax = min(max_disp - 1, x);
@@ -174,12 +172,12 @@ __global__ __launch_bounds__(EXT_THREADS) void disp_ext_bruteforce_kernel(
                 // R tile column of image column c: c - (x0 - r - (max_disp-1))
                 const int rc = lx + r + (max_disp - 1) - d;  // column of x1 = x - d
                 if (Rt[(ly + r) * rw + rc] == 0) continue;
-                const int dx_lo = max(-r, d - x);
                 unsigned cost = 0;
-                for (int dy = dy_lo; dy <= dy_hi; ++dy) {
+                // taps outside either image read the zero fill of the tiles
+                for (int dy = -r; dy <= r; ++dy) {
                     const uint8_t *lrow = Lt + (ly + r + dy) * lw + lx + r;
                     const uint8_t *rrow = Rt + (ly + r + dy) * rw + rc;
-                    for (int dx = dx_lo; dx <= dx_hi; ++dx) {
+                    for (int dx = -r; dx <= r; ++dx) {
                         const int a = lrow[dx], b = rrow[dx];
                         const unsigned ad = (unsigned)(a > b ? a - b : b - a);
                         cost += SSD ? ad * ad : ad;
@@ -198,6 +196,367 @@ __global__ __launch_bounds__(EXT_THREADS) void disp_ext_bruteforce_kernel(
         else
             reinterpret_cast<uint16_t *>(orow)[x] = (uint16_t)(v & 0xFFFF);
     }
+}
+
+
+// ---------------------------------------------------------------------------
+// D1-ext, sliding-sum kernel (SAD, window radius 0..4, any max_disp).
+//
+// Work decomposition
+//   workgroup = one tile of 256 image columns x one band of `bh` output rows;
+//   wave w of the workgroup owns the 16 disparities d in [dbase+16w, dbase+16w+16);
+//   lane l of a wave owns the 4 adjacent columns x0+4l .. x0+4l+3.
+// Rows are streamed top to bottom through an LDS ring of BAND_RING rows.  A ring
+// row holds the img0 row (256 columns), the img1 row (256 + 16*nw columns to the
+// left) and a candidate-validity mask row, all as 32-bit words with the pixel
+// value pre-shifted by BAND_SH bits, so that every cost this kernel forms is
+// already in the upper bits of its winner-take-all key.
+//
+// Per lane, per (d, column): V[d][c] is the running column sum of |img1 - img0|
+// over the window's rows.  A new row is added with one v_sad_u32 (|a-b|+acc), the
+// row leaving the window is subtracted (v_sad_u32 + v_sub); both operands come
+// from registers filled by 128-bit LDS reads (one lane = 4 columns = one b128).
+// The horizontal window sum slides across the lane's 4 columns and takes the
+// columns it lacks from the neighbouring lanes with wave_shr:1 / wave_shl:1 DPP
+// adds (window radius <= 4 => one lane to each side).  The key
+//     (cost << BAND_SH) | (4095 - d) | mask(img1[y][x-d] == 0 or x-d < 0)
+// is reduced with v_min3_u32 over the wave's 16 disparities, then across the
+// workgroup's waves with one LDS atomic min per pixel: smallest cost wins, equal
+// costs go to the larger d = the lower x1, which is the reference's strict-'<'
+// first-wins order for an ascending-x1 scan.
+// ---------------------------------------------------------------------------
+
+constexpr int BAND_RING = 16;        // LDS ring rows; needs win + 2 <= BAND_RING
+constexpr int BAND_ND = 16;          // disparities per wave
+constexpr int BAND_COLS = 256;       // columns per tile (64 lanes x 4)
+constexpr unsigned BAND_SH = 12;     // key = cost << 12 | (4095 - d)
+constexpr unsigned BAND_LOW = (1u << BAND_SH) - 1;
+constexpr unsigned BAND_INIT = 0xFFFFFFFEu;  // "no candidate yet": above every valid key
+constexpr unsigned BAND_MASKED = 0xFFFFFFFFu;
+constexpr int BAND_MAX_WAVES = 16;
+
+// |a - b| + c in one instruction.  Written as asm because hipcc only matches the
+// pattern when the result is used as a sum; the "row leaving the window" form
+// (V -= |a-b|) otherwise becomes max, min and two subtractions.
+__device__ __forceinline__ unsigned sad_u32(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned sad_u32_0(unsigned a, unsigned b)
+{
+    unsigned r;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned min3_u32(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// One ds_read_b128.  The empty asm keeps the 16-byte load whole: without it the
+// element extracts are scalarised and re-merged as ds_read2_b32 pairs.
+__device__ __forceinline__ u32x4 lds_read_b128(const u32x4 *p)
+{
+    u32x4 t = *p;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+__device__ __forceinline__ unsigned from_left(unsigned v)
+{
+    // lane l receives lane l-1's value (wave_shr:1); folded into the consuming add
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned from_right(unsigned v)
+{
+    // lane l receives lane l+1's value (wave_shl:1)
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+}
+
+struct BandArgs {
+    const uint8_t *img0;
+    const uint8_t *img1;
+    int w, h;
+    size_t stride, pair_stride;
+    int row0, rows, bh;
+    int D;      // total number of disparities
+    int dbase;  // first disparity of this pass
+    unsigned *keys;  // per-pixel best keys carried between passes (nullptr if one pass)
+    int first_pass, last_pass;
+    uint8_t *out;
+    size_t out_stride, out_pair_stride;
+    int out_bytes;
+};
+
+template <int R>
+__global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs a)
+{
+    constexpr int WIN = 2 * R + 1;
+    constexpr int HL = (R + 3) / 4;  // halo lanes on each side of the tile
+    constexpr int TILE_OUT = BAND_COLS - 8 * HL;
+    static_assert(WIN + 2 <= BAND_RING, "ring too small");
+
+    extern __shared__ u32x4 band_lds4[];
+    const int nw = blockDim.x >> 6;
+    const int rw4 = BAND_COLS / 4 + (BAND_ND / 4) * nw;  // img1 row length in 4-column groups
+    const int rw = 4 * rw4;                              // img1 columns per ring row
+    u32x4 *Lrow4 = band_lds4;                            // [RING][64]
+    u32x4 *Rrow4 = Lrow4 + BAND_RING * (BAND_COLS / 4);  // [RING][rw4]
+    u32x4 *Mrow4 = Rrow4 + BAND_RING * rw4;              // [RING][rw4]
+    unsigned *Lrow = reinterpret_cast<unsigned *>(Lrow4);
+    unsigned *Rrow = reinterpret_cast<unsigned *>(Rrow4);
+    unsigned *Mrow = reinterpret_cast<unsigned *>(Mrow4);
+    unsigned *best = reinterpret_cast<unsigned *>(Mrow4 + BAND_RING * rw4);  // [2][256]
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const size_t pair = blockIdx.z;
+    const uint8_t *i0 = a.img0 + pair * a.pair_stride;
+    const uint8_t *i1 = a.img1 + pair * a.pair_stride;
+    const int w = a.w, h = a.h;
+    const int x0 = (int)blockIdx.x * TILE_OUT - 4 * HL;  // image column of lane 0, column 0
+    const int yb = a.row0 + (int)blockIdx.y * a.bh;      // first output row of the band
+    const int yend = min(yb + a.bh, a.row0 + a.rows);    // one past the last output row
+    const int dB = a.dbase + BAND_ND * wave;             // this wave's first disparity
+    const bool active = dB < a.D;  // waves past the last disparity block only help fill the ring
+    const int rbase = x0 - a.dbase - BAND_ND * nw;       // image column of Rrow[.][0]
+    // this lane's first img1 word: column x0 + 4*lane - dB - 16
+    const int roff4 = lane + (BAND_ND / 4) * (nw - 1 - wave);
+
+    for (int i = tid; i < 2 * BAND_COLS; i += blockDim.x) best[i] = BAND_INIT;
+
+    // ---- ring fill: one image row -> slot ---------------------------------
+    // each thread carries at most FILL_MAX words between its global loads (issued
+    // at the top of a step) and its LDS stores (issued just before the barrier)
+    constexpr int FILL_MAX = 2;
+    unsigned fill_l = 0, fill_r[FILL_MAX] = {0, 0};
+    auto fill_load = [&](int yy) {
+        const bool rowok = yy >= 0 && yy < h;
+        if (tid < BAND_COLS) {
+            const int x = x0 + tid;
+            fill_l = (rowok && x >= 0 && x < w) ? i0[(size_t)yy * a.stride + x] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < FILL_MAX; ++k) {
+            const int i = tid + k * (int)blockDim.x;
+            const int x = rbase + i;
+            fill_r[k] = (i < rw && rowok && x >= 0 && x < w) ? i1[(size_t)yy * a.stride + x] : 0u;
+        }
+    };
+    auto fill_store = [&](int yy) {
+        const int slot = (yy + 64) & (BAND_RING - 1);
+        if (tid < BAND_COLS) Lrow[slot * BAND_COLS + tid] = fill_l << BAND_SH;
+#pragma unroll
+        for (int k = 0; k < FILL_MAX; ++k) {
+            const int i = tid + k * (int)blockDim.x;
+            if (i < rw) {
+                Rrow[slot * rw + i] = fill_r[k] << BAND_SH;
+                Mrow[slot * rw + i] = fill_r[k] ? 0u : BAND_MASKED;
+            }
+        }
+    };
+
+    unsigned V[BAND_ND][4];
+#pragma unroll
+    for (int dd = 0; dd < BAND_ND; ++dd)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) V[dd][c] = 0;
+
+    const int ys0 = yb - R, ys1 = yend - 1 + R;  // streamed rows
+    fill_load(ys0);
+    fill_store(ys0);
+    __syncthreads();
+
+    for (int ys = ys0; ys <= ys1; ++ys) {
+        if (ys < ys1) fill_load(ys + 1);
+
+        // ---- add the row entering the window --------------------------------
+        if (active) {
+            const int slot = (ys + 64) & (BAND_RING - 1);
+            const u32x4 lv4 = lds_read_b128(Lrow4 + slot * (BAND_COLS / 4) + lane);
+            const u32x4 *rp = Rrow4 + slot * rw4 + roff4;
+            unsigned rv[20];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const u32x4 t = lds_read_b128(rp + j);
+                rv[4 * j] = t.x; rv[4 * j + 1] = t.y; rv[4 * j + 2] = t.z; rv[4 * j + 3] = t.w;
+            }
+            const unsigned lv[4] = {lv4.x, lv4.y, lv4.z, lv4.w};
+#pragma unroll
+            for (int dd = 0; dd < BAND_ND; ++dd)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (R == 0)
+                        V[dd][c] = sad_u32_0(rv[16 + c - dd], lv[c]);
+                    else
+                        V[dd][c] = sad_u32(rv[16 + c - dd], lv[c], V[dd][c]);
+                }
+        }
+        // ---- subtract the row leaving the window ----------------------------
+        if (active && R > 0 && ys - WIN >= ys0) {
+            const int slot = (ys - WIN + 64) & (BAND_RING - 1);
+            const u32x4 lv4 = lds_read_b128(Lrow4 + slot * (BAND_COLS / 4) + lane);
+            const u32x4 *rp = Rrow4 + slot * rw4 + roff4;
+            unsigned rv[20];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const u32x4 t = lds_read_b128(rp + j);
+                rv[4 * j] = t.x; rv[4 * j + 1] = t.y; rv[4 * j + 2] = t.z; rv[4 * j + 3] = t.w;
+            }
+            const unsigned lv[4] = {lv4.x, lv4.y, lv4.z, lv4.w};
+#pragma unroll
+            for (int dd = 0; dd < BAND_ND; ++dd)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) V[dd][c] -= sad_u32_0(rv[16 + c - dd], lv[c]);
+        }
+
+        // ---- output row y = ys - R: window sums, keys, winner-take-all --------
+        const int y = ys - R;
+        if (active && y >= yb) {
+            const int slot = (y + 64) & (BAND_RING - 1);
+            const u32x4 *mp = Mrow4 + slot * rw4 + roff4;
+            unsigned mv[20];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const u32x4 t = lds_read_b128(mp + j);
+                mv[4 * j] = t.x; mv[4 * j + 1] = t.y; mv[4 * j + 2] = t.z; mv[4 * j + 3] = t.w;
+            }
+            unsigned m[4] = {BAND_MASKED, BAND_MASKED, BAND_MASKED, BAND_MASKED};
+            unsigned pend[4];
+#pragma unroll
+            for (int dd = 0; dd < BAND_ND; ++dd) {
+                // disparities past D (partial last block) get an all-ones key (wave-uniform)
+                const unsigned low = dB + dd < a.D ? BAND_LOW - (unsigned)(dB + dd) : BAND_MASKED;
+                unsigned cost[4];
+                if (R == 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) cost[c] = V[dd][c];
+                } else {
+                    // cost[c] = sum of V over columns c-R .. c+R; columns < 0 live in the
+                    // left neighbour lane (as its column +4), columns > 3 in the right one
+                    unsigned own = V[dd][0];
+#pragma unroll
+                    for (int c = 1; c <= (R < 3 ? R : 3); ++c) own += V[dd][c];
+                    unsigned suffix = V[dd][3];  // columns 4-R .. 3, wanted by the right neighbour
+#pragma unroll
+                    for (int c = 2; c >= 4 - R; --c) suffix += V[dd][c];
+                    cost[0] = own + from_left(suffix);
+                    if (R == 4) cost[0] += from_right(V[dd][0]);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        // slide: drop column c-R, take column c+1+R
+                        const int drop = c - R, take = c + 1 + R;
+                        unsigned t = cost[c];
+                        t -= drop >= 0 ? V[dd][drop] : from_left(V[dd][drop + 4]);
+                        t += take <= 3 ? V[dd][take] : from_right(V[dd][take - 4]);
+                        cost[c + 1] = t;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned key = cost[c] | mv[16 + c - dd] | low;
+                    if (dd & 1)
+                        m[c] = min3_u32(m[c], pend[c], key);
+                    else
+                        pend[c] = key;
+                }
+            }
+            unsigned *b = best + (y & 1) * BAND_COLS + 4 * lane;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) atomicMin(b + c, m[c]);
+        }
+
+        if (ys < ys1) fill_store(ys + 1);
+        __syncthreads();
+
+        // ---- write out row y (all waves have contributed) ---------------------
+        if (y >= yb && tid < BAND_COLS) {
+            const int c = tid;
+            unsigned key = best[(y & 1) * BAND_COLS + c];
+            best[(y & 1) * BAND_COLS + c] = BAND_INIT;
+            const int x = x0 + c;
+            if ((c >> 2) >= HL && (c >> 2) < 64 - HL && x < w) {
+                const size_t pix = (size_t)(y - a.row0) * w + x;
+                unsigned *kp = a.keys ? a.keys + pair * (size_t)a.rows * w + pix : nullptr;
+                if (kp && !a.first_pass) key = min(key, *kp);
+                if (!a.last_pass) {
+                    *kp = key;
+                } else {
+                    const int slot = (y + 64) & (BAND_RING - 1);
+                    int v;
+                    if (Lrow[slot * BAND_COLS + c] == 0)
+                        v = 0;  // centre pixel of img0 is 0: output stays 0
+                    else if (key >= BAND_INIT)
+                        v = x;  // no valid candidate: xBest stays 0
+                    else
+                        v = (int)(BAND_LOW - (key & BAND_LOW));  // d = x - xBest
+                    uint8_t *orow = a.out + pair * a.out_pair_stride + (size_t)(y - a.row0) * a.out_stride;
+                    if (a.out_bytes == 1)
+                        orow[x] = (uint8_t)(v & 0xFF);
+                    else
+                        reinterpret_cast<uint16_t *>(orow)[x] = (uint16_t)(v & 0xFFFF);
+                }
+            }
+        }
+    }
+}
+
+template <int R>
+int launch_band(stx_ctx *ctx, BandArgs a, int n_pairs)
+{
+    constexpr int HL = (R + 3) / 4;
+    constexpr int TILE_OUT = BAND_COLS - 8 * HL;
+    const int xt = (a.w + TILE_OUT - 1) / TILE_OUT;
+    const int passD = BAND_ND * BAND_MAX_WAVES;  // disparities per pass
+    const int npass = (a.D + passD - 1) / passD;
+    // band height: trade the 2R warm-up rows against filling the CUs evenly
+    const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    int best_bh = a.rows;
+    double best_t = 1e300;
+    for (int bh = 8; bh <= 512; bh += 4) {
+        const int bands = (a.rows + bh - 1) / bh;
+        const long wgs = (long)xt * bands * n_pairs;
+        const long rounds = (wgs + cus - 1) / cus;
+        const int last = a.rows - (bands - 1) * bh;
+        const double t = (double)rounds * (bh + 2 * R + 1) + 0.001 * (bh - last);
+        if (t < best_t) { best_t = t; best_bh = bh; }
+        if (bh >= a.rows) break;
+    }
+    a.bh = best_bh;
+    const int bands = (a.rows + a.bh - 1) / a.bh;
+    if (bands > 65535 || n_pairs > 65535) return STX_ERR_TOO_LARGE;
+    if (npass > 1) {
+        int err;
+        a.keys = (unsigned *)stx_workspace(ctx, STX_SLOT_DISP_KEYS, sizeof(unsigned) * (size_t)n_pairs * a.rows * a.w, &err);
+        if (!a.keys) return err;
+    } else {
+        a.keys = nullptr;
+    }
+    for (int p = 0; p < npass; ++p) {
+        a.dbase = p * passD;
+        const int dleft = a.D - a.dbase;
+        // at least 4 waves: the ring fill needs 256 threads for the img0 row
+        const int nw = max(4, (min(dleft, passD) + BAND_ND - 1) / BAND_ND);
+        a.first_pass = p == 0;
+        a.last_pass = p == npass - 1;
+        const int rw = BAND_COLS + BAND_ND * nw;
+        const size_t lds = sizeof(unsigned) * ((size_t)BAND_RING * (BAND_COLS + 2 * rw) + 2 * BAND_COLS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(disp_band_kernel<R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(disp_band_kernel<R>, dim3(xt, bands, n_pairs), dim3(64 * nw), lds,
+                           ctx->stream, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return STX_OK;
 }
 
 }  // namespace
@@ -226,6 +585,20 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
 
     const int r = win / 2;
     const int D = max_disp < w ? max_disp : w;  // candidates beyond column 0 do not exist
+    if (cost_mode == STX_COST_SAD && r <= 4 && D <= 4096 && !ctx->force_bruteforce) {
+        BandArgs a;
+        a.img0 = d_img0; a.img1 = d_img1; a.w = w; a.h = h; a.stride = stride;
+        a.pair_stride = pair_stride; a.row0 = row0; a.rows = rows; a.bh = rows; a.D = D;
+        a.dbase = 0; a.keys = nullptr; a.first_pass = 1; a.last_pass = 1; a.out = o;
+        a.out_stride = out_stride; a.out_pair_stride = out_pair_stride; a.out_bytes = out_bytes;
+        switch (r) {
+        case 0: return launch_band<0>(ctx, a, n_pairs);
+        case 1: return launch_band<1>(ctx, a, n_pairs);
+        case 2: return launch_band<2>(ctx, a, n_pairs);
+        case 3: return launch_band<3>(ctx, a, n_pairs);
+        default: return launch_band<4>(ctx, a, n_pairs);
+        }
+    }
     const size_t lds = (size_t)(EXT_TX + 2 * r) * (EXT_TY + 2 * r) +
                        (size_t)(EXT_TX + 2 * r + D - 1) * (EXT_TY + 2 * r);
     if (lds > 64 * 1024) return STX_ERR_TOO_LARGE;

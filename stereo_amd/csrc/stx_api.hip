@@ -91,6 +91,14 @@ extern "C" int stx_set_match_algo(stx_ctx *ctx, int algo)
     return STX_OK;
 }
 
+extern "C" int stx_set_disparity_algo(stx_ctx *ctx, int algo)
+{
+    if (!ctx) return STX_ERR_INVALID_ARG;
+    if (algo != STX_DISP_AUTO && algo != STX_DISP_BRUTEFORCE) return STX_ERR_INVALID_ARG;
+    ctx->force_bruteforce = algo == STX_DISP_BRUTEFORCE;
+    return STX_OK;
+}
+
 void *stx_workspace(stx_ctx *ctx, int slot, size_t bytes, int *err)
 {
     *err = STX_OK;

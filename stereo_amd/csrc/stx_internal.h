@@ -12,6 +12,7 @@ enum stx_slot {
     STX_SLOT_IMG0 = 0,   // host-API staging: first input image(s)
     STX_SLOT_IMG1,       // host-API staging: second input image / rectify dst
     STX_SLOT_OUT,        // host-API staging: output
+    STX_SLOT_DISP_KEYS,  // disparity: per-pixel best keys carried between passes (D > 256)
     STX_SLOT_DESC1,      // host-API staging: list1 descriptors
     STX_SLOT_DESC2,      // host-API staging: list2 descriptors
     STX_SLOT_SMALL,      // host-API staging: scores + per-query outputs
@@ -27,6 +28,7 @@ struct stx_ctx {
     int device;
     hipStream_t stream;
     int match_algo;
+    int force_bruteforce;  // tests: route every D1-ext call to the tap-by-tap kernel
     int num_cus;
     void *slot_ptr[STX_SLOT_COUNT];
     size_t slot_bytes[STX_SLOT_COUNT];

@@ -84,12 +84,31 @@ EXT_CASES = [(1, 1, 0), (1, 16, 0), (1, 64, 1), (3, 5, 0), (3, 16, 0), (5, 24, 0
              (7, 33, 0), (9, 32, 0), (9, 64, 1), (11, 20, 0), (15, 40, 0), (9, 256, 0)]
 
 
+@pytest.mark.parametrize("algo", [api.DISP_AUTO, api.DISP_BRUTEFORCE])
 @pytest.mark.parametrize("win,D,cm", EXT_CASES)
-def test_disparity_ext_matches_oracle(ctx, oracle, win, D, cm):
+def test_disparity_ext_matches_oracle(ctx, oracle, win, D, cm, algo):
     h, w = (37, 150) if D <= 64 else (21, 300)
     a, b = _rand_pair(win * 1000 + D * 7 + cm, h, w)
     want = oracle.disparity_ext(a, b, win, D, cm)
-    assert (ctx.disparity(a, b, win=win, max_disp=D, cost_mode=cm) == want).all()
+    ctx.set_disparity_algo(algo)
+    try:
+        got = ctx.disparity(a, b, win=win, max_disp=D, cost_mode=cm)
+    finally:
+        ctx.set_disparity_algo(api.DISP_AUTO)
+    assert (got == want).all(), np.argwhere(got != want)[:10]
+
+
+@pytest.mark.parametrize("win", [1, 3, 5, 7, 9])
+@pytest.mark.parametrize("h,w,D", [(40, 300, 16), (130, 520, 100), (70, 777, 256), (33, 1100, 300),
+                                   (20, 900, 700)])
+def test_disparity_sliding_kernel_tiles_and_passes(ctx, oracle, win, h, w, D):
+    """Several 248/256-column tiles, several row bands, partial last 16-disparity
+    block (D=100, 300, 700) and the multi-pass path (D > 256)."""
+    a, b = _rand_pair(win + h + w + D, h, w, zero=0.03)
+    dt = np.uint16 if D > 256 else np.uint8
+    want = oracle.disparity_ext(a, b, win, D, 0, dt, sliding=True)
+    got = ctx.disparity(a, b, win=win, max_disp=D, out_dtype=dt)
+    assert (got == want).all(), np.argwhere(got != want)[:10]
 
 
 @pytest.mark.parametrize("h,w,win,D", [(1, 1, 3, 4), (2, 3, 5, 8), (5, 64, 9, 16), (17, 65, 9, 16),
