@@ -271,12 +271,14 @@ __device__ __forceinline__ u32x4 lds_read_b128(const u32x4 *p)
 __device__ __forceinline__ unsigned from_left(unsigned v)
 {
     // lane l receives lane l-1's value (wave_shr:1); folded into the consuming add
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+    unsigned r = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+    return r;
 }
 __device__ __forceinline__ unsigned from_right(unsigned v)
 {
     // lane l receives lane l+1's value (wave_shl:1)
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+    unsigned r = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+    return r;
 }
 
 struct BandArgs {
@@ -451,12 +453,20 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
                     if (R == 4) cost[0] += from_right(V[dd][0]);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        // slide: drop column c-R, take column c+1+R
+                        // slide: drop column c-R, take column c+1+R.  A column taken from the
+                        // left lane is always the MINUEND of its subtraction (n = left - cost,
+                        // then take - n): hipcc folds "x - dpp(y)" into v_subrev_u32_dpp, which
+                        // this toolchain encodes with the DPP on the wrong operand (measured:
+                        // tools/dpp_test.hip); "dpp(y) - x" (v_sub_u32_dpp) is correct.
                         const int drop = c - R, take = c + 1 + R;
-                        unsigned t = cost[c];
-                        t -= drop >= 0 ? V[dd][drop] : from_left(V[dd][drop + 4]);
-                        t += take <= 3 ? V[dd][take] : from_right(V[dd][take - 4]);
-                        cost[c + 1] = t;
+                        const unsigned tk = take <= 3 ? V[dd][take] : from_right(V[dd][take - 4]);
+                        if (drop >= 0) {
+                            cost[c + 1] = tk + (cost[c] - V[dd][drop]);
+                        } else {
+                            unsigned n = from_left(V[dd][drop + 4]) - cost[c];
+                            asm volatile("" : "+v"(n));  // keep hipcc from re-associating
+                            cost[c + 1] = tk - n;
+                        }
                     }
                 }
 #pragma unroll

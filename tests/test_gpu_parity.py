@@ -196,15 +196,6 @@ def test_disparity_full_size_properties(ctx, oracle):
     # property 1: the scan is row-local -- permuting rows permutes the output
     perm = np.random.RandomState(1).permutation(h)
     assert (ctx.disparity(l[perm], r[perm]) == got[perm]).all()
-    # property 2: output depends only on (pixel value, row of img1): equal pixels
-    # in one row share xBest, so out(x) = |xBest - x| mod 256 is consistent
-    y = 997
-    for v in (17, 100, 200):
-        xs = np.nonzero(l[y] == v)[0]
-        if len(xs) > 1:
-            xb = oracle.disparity_ext(l[y:y + 1, xs[:1]], r[y:y + 1], 1, 0) if False else None
-            cand = [(x - int(got[y, x])) for x in xs] + [(x + int(got[y, x])) for x in xs]
-            assert len(cand) > 0
     # windowed kernel at full size on sampled rows (win 9 needs rows y-4..y+4)
     gw = ctx.disparity(l, r, win=9, max_disp=256)
     for y0 in (0, 1000, h - 9):
@@ -301,9 +292,17 @@ def test_rectify_dev_batch_full_size(ctx, oracle):
 # ------------------------------------------------------------------ M ------
 
 def _match_equal(got, want):
+    """Indices and status byte-equal; distances bit-equal, except that any NaN
+    matches any NaN (x86 and gfx950 differ in the sign/payload of generated NaNs,
+    which nothing in the reference observes)."""
     names = ["closest", "second", "min_dist", "second_dist", "status"]
     for n, g, w in zip(names, got, want):
-        assert g.tobytes() == w.tobytes(), "%s differs at %s" % (n, np.nonzero(g != w)[0][:8])
+        if g.dtype == np.float32:
+            gb, wb = g.view(np.uint32), w.view(np.uint32)
+            ok = (gb == wb) | (np.isnan(g) & np.isnan(w))
+            assert ok.all(), "%s differs at %s" % (n, np.nonzero(~ok)[0][:8])
+        else:
+            assert g.tobytes() == w.tobytes(), "%s differs at %s" % (n, np.nonzero(g != w)[0][:8])
 
 
 ALGOS = [api.MATCH_EXACT, api.MATCH_MFMA, api.MATCH_AUTO]
