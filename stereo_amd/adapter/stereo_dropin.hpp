@@ -1,0 +1,118 @@
+// stereo_dropin.hpp -- the reference's three hot-path functions, re-implemented on
+// top of libstereo_hip.so.  Header-only; include it INSTEAD of the bodies at
+//   stereo/Features.cpp:1020-1079      (MatchDescriptors)
+//   stereo/Stereography.cpp:596-631    (RectifyImage)
+//   stereo/Stereography.cpp:649-691    (ComputeDepthImage)
+// The including translation unit must already see the reference's `Feature`
+// (stereo/Features.h:52-84), cv::Mat and Eigen::Matrix3f.  Signatures, ownership and
+// printed lines are the reference's.
+#pragma once
+
+#include <cstdint>
+#include <cstdlib>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "stereo_hip.h"
+
+namespace stereo_hip_dropin {
+
+// One context per thread, created on first use on HIP device STEREO_HIP_DEVICE (default 0).
+inline stx_ctx *context()
+{
+    thread_local stx_ctx *ctx = nullptr;
+    if (!ctx) {
+        const char *dev = std::getenv("STEREO_HIP_DEVICE");
+        const int rc = stx_create(&ctx, dev ? std::atoi(dev) : 0);
+        if (rc != STX_OK) throw std::runtime_error(std::string("stx_create: ") + stx_error_string(rc));
+    }
+    return ctx;
+}
+
+inline void check(int rc, const char *what)
+{
+    // the reference has no error path; a GPU failure must not pass silently
+    if (rc != STX_OK) throw std::runtime_error(std::string(what) + ": " + stx_error_string(rc));
+}
+
+}  // namespace stereo_hip_dropin
+
+// Features.h:195-196.  Lists are taken by value as in the reference (callee-owned copies).
+inline std::vector<std::pair<Feature, Feature> > MatchDescriptors(
+    std::vector<Feature> list1, std::vector<Feature> list2, float distLimitBetweenMatches)
+{
+    using namespace stereo_hip_dropin;
+    const int n1 = (int)list1.size(), n2 = (int)list2.size();
+    // AoS Feature (540 B, descriptor at offset 20) -> SoA descriptor / score arrays
+    std::vector<float> d1((size_t)n1 * STX_DESC_LEN), d2((size_t)n2 * STX_DESC_LEN), s1(n1), s2(n2);
+    for (int i = 0; i < n1; ++i) {
+        for (int k = 0; k < STX_DESC_LEN; ++k) d1[(size_t)i * STX_DESC_LEN + k] = list1[i].desc.vec[k];
+        s1[i] = list1[i].score;
+    }
+    for (int j = 0; j < n2; ++j) {
+        for (int k = 0; k < STX_DESC_LEN; ++k) d2[(size_t)j * STX_DESC_LEN + k] = list2[j].desc.vec[k];
+        s2[j] = list2[j].score;
+    }
+    std::vector<int32_t> closest(n1), second(n1);
+    std::vector<float> minDist(n1), secondDist(n1);
+    std::vector<uint8_t> status(n1);
+    check(stx_match(context(), d1.data(), s1.data(), n1, d2.data(), s2.data(), n2,
+                    distLimitBetweenMatches, closest.data(), second.data(), minDist.data(),
+                    secondDist.data(), status.data()),
+          "stx_match");
+    std::vector<std::pair<Feature, Feature> > matches;
+    for (int i = 0; i < n1; ++i) {
+        if (status[i] == STX_MATCH_FAILED) {
+            std::cout << "Error: failed to match feature " << i << std::endl;  // Features.cpp:1052
+            continue;
+        }
+        if (status[i] != STX_MATCH_ACCEPTED) continue;
+        // Features.cpp:1070-1074: both copies carry the distance
+        list1[i].distFromBestMatch = minDist[i];
+        list2[closest[i]].distFromBestMatch = minDist[i];
+        matches.push_back(std::make_pair(list1[i], list2[closest[i]]));
+    }
+    return matches;
+}
+
+// Stereography.h:48-51.  H is the forward homography; `rectified` is in/out.
+inline void RectifyImage(const cv::Mat &original, cv::Mat &rectified, const Eigen::Matrix3f &H)
+{
+    using namespace stereo_hip_dropin;
+    float h[9], hinv[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) h[r * 3 + c] = H(r, c);
+    check(stx_invert_homography(h, hinv), "stx_invert_homography");  // H.inverse(), :617
+    check(stx_rectify_u8(context(), original.data, original.cols, original.rows, (size_t)original.step,
+                         rectified.data, rectified.cols, rectified.rows, (size_t)rectified.step, hinv,
+                         STX_RECT_PRESERVE_DST),
+          "stx_rectify_u8");
+}
+
+// Stereography.h:53-55.
+inline cv::Mat ComputeDepthImage(const cv::Mat &img0, const cv::Mat &img1)
+{
+    using namespace stereo_hip_dropin;
+    if (img0.cols != img1.cols || img0.rows != img1.rows) {
+        std::cout << "Cannot compute depth!" << std::endl;  // Stereography.cpp:657
+        return cv::Mat(cv::Size(0, 0), CV_8U);
+    }
+    cv::Mat depth = cv::Mat::zeros(cv::Size(img0.cols, img0.rows), CV_8U);
+    if (img0.step == img1.step) {
+        check(stx_disparity_u8(context(), img0.data, img1.data, img0.cols, img0.rows, (size_t)img0.step,
+                               1, 0, STX_COST_SAD, depth.data, (size_t)depth.step),
+              "stx_disparity_u8");
+    } else {
+        // different pitches: repack img1 to img0's pitch
+        std::vector<uint8_t> tmp((size_t)img0.step * img0.rows);
+        for (int y = 0; y < img1.rows; ++y)
+            for (int x = 0; x < img1.cols; ++x) tmp[(size_t)y * img0.step + x] = img1.data[(size_t)y * img1.step + x];
+        check(stx_disparity_u8(context(), img0.data, tmp.data(), img0.cols, img0.rows, (size_t)img0.step,
+                               1, 0, STX_COST_SAD, depth.data, (size_t)depth.step),
+              "stx_disparity_u8");
+    }
+    return depth;
+}
