@@ -54,10 +54,14 @@ constexpr int EXACT_THREADS = 64;
 __global__ __launch_bounds__(EXACT_THREADS) void match_exact_kernel(
     const float *__restrict__ desc1, const float *__restrict__ score1, int n1,
     const float *__restrict__ desc2, const float *__restrict__ score2, int n2, float dist_limit,
-    const int32_t *__restrict__ query_list, int n_queries, int32_t *__restrict__ closest_out,
+    const int32_t *__restrict__ query_list, const int *__restrict__ n_queries_dev, int n_queries_host,
+    int32_t *__restrict__ closest_out,
     int32_t *__restrict__ second_out, float *__restrict__ min_dist_out,
     float *__restrict__ second_dist_out, uint8_t *__restrict__ status_out)
 {
+    // the overflow pass reads its query count from device memory (written by the replay kernel)
+    const int n_queries = n_queries_dev ? *n_queries_dev : n_queries_host;
+    if ((int)(blockIdx.x * EXACT_THREADS) >= n_queries) return;
     const int slot = blockIdx.x * EXACT_THREADS + threadIdx.x;
     const bool active = slot < n_queries;
     // inactive lanes shadow the last query so that the row loop stays uniform
@@ -113,7 +117,286 @@ __global__ __launch_bounds__(EXACT_THREADS) void match_exact_kernel(
         status_out[i] = match_status(closest, second, min_dist, second_dist, score1[i], score2, dist_limit);
 }
 
+
+// ---------------------------------------------------------------------------
+// MFMA prefilter + exact replay.
+//
+// The reference's scan only changes state at strict running minima ("records")
+// of dist(j), j ascending.  Phase 1 computes approximate squared distances
+//     d~(i,j) = (|a_i|^2 + |b_j|^2) - 2 a_i.b_j
+// with fp32 MFMA (v_mfma_f32_32x32x2_f32: an exact-fp32 fma chain) and emits, per
+// query, every j that COULD be a record: with eps(i,j) = C*(|a|^2+|b|^2) + tiny a
+// bound on |d~ - norm_ref| (norm_ref = the fp32 value the reference holds before
+// its sqrt; see DESIGN.md for the derivation of C), j is emitted unless
+//     d~ - eps  >  min over the j' < j already seen by this lane of (d~' + eps').
+// A true record has norm_ref(j) < norm_ref(j') for every j' < j (sqrt is
+// monotonic), hence d~-eps <= norm_ref(j) < norm_ref(j') <= d~'+eps': it is never
+// filtered.  NaN/inf anywhere makes the comparison false, i.e. emits.  Phase 2
+// sorts each query's candidates by j, recomputes their distances in the
+// reference's exact operation order and replays the reference scan over them;
+// since the prefix minimum is always attained at a record and every record is a
+// candidate, closest / second / minDist come out bit-identical.  A query whose
+// candidate list overflows is redone by the exact kernel above.
+// ---------------------------------------------------------------------------
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MF_WAVES = 4;            // waves per workgroup
+constexpr int MF_QW = 64;              // queries per wave (two 32-wide MFMA column blocks)
+constexpr int MF_QB = MF_WAVES * MF_QW;  // queries per workgroup
+constexpr int MF_JB = 32;              // list2 rows per MFMA row block
+constexpr int MF_TJ = 2;               // row blocks per LDS tile
+constexpr int MF_TILE_ROWS = MF_JB * MF_TJ;
+constexpr int MF_BLOCK_FLOATS = MF_JB * K;  // 4096 floats = 16 KiB per row block
+constexpr int MF_CAP = 256;            // candidate slots per query
+constexpr float MF_C = 6.103515625e-05f;  // 2^-14 >= 523 * 2^-24
+constexpr float MF_TINY = 1e-37f;      // covers underflow in either computation
+
+// list2 -> MFMA A-operand fragment order, rows padded with zeros to n2pad:
+//   frag[((jb*16 + g)*64 + lane)*4 + t] = desc2[jb*32 + (lane&31)][2*(4g+t) + (lane>>5)]
+__global__ __launch_bounds__(256) void match_prep_frag_kernel(const float *__restrict__ desc2, int n2,
+                                                              int n2pad, float *__restrict__ frag)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // one float4 of frag
+    const size_t total = (size_t)n2pad * K / 4;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int g = (int)((idx >> 6) & 15);
+    const size_t jb = idx >> 10;
+    const size_t j = jb * MF_JB + (lane & 31);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < (size_t)n2) {
+        const float *row = desc2 + j * K + 8 * g + (lane >> 5);
+        v = make_float4(row[0], row[2], row[4], row[6]);
+    }
+    reinterpret_cast<float4 *>(frag)[idx] = v;
+}
+
+// squared norms (any summation order: covered by the error bound); padding rows get 0
+__global__ __launch_bounds__(256) void match_norm_kernel(const float *__restrict__ desc, int n, int npad,
+                                                         float *__restrict__ norm2)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= npad) return;
+    float s = 0.f;
+    if (r < n) {
+        const float4 *row = reinterpret_cast<const float4 *>(desc + (size_t)r * K);
+#pragma unroll 8
+        for (int k = 0; k < K / 4; ++k) {
+            const float4 v = row[k];
+            s = fmaf(v.x, v.x, s);
+            s = fmaf(v.y, v.y, s);
+            s = fmaf(v.z, v.z, s);
+            s = fmaf(v.w, v.w, s);
+        }
+    }
+    norm2[r] = s;
+}
+
+__global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_kernel(
+    const float *__restrict__ desc1, const float *__restrict__ qnorm, int n1,
+    const float *__restrict__ frag, const float *__restrict__ bnorm, int n2, int tiles_total,
+    int tiles_per_seg, int *__restrict__ cand_count, int *__restrict__ cand)
+{
+    __shared__ __attribute__((aligned(16))) float tile[2][MF_TJ * MF_BLOCK_FLOATS];  // 64 KiB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const int q0i = blockIdx.x * MF_QB + wave * MF_QW + col;  // column block 0
+    const int q1i = q0i + 32;                                   // column block 1
+
+    // query fragments: B operand, lane holds q[i][2s + half], s = 0..63
+    float qa[64], qb[64];
+    {
+        const bool ok0 = q0i < n1, ok1 = q1i < n1;
+        const float4 *r0 = reinterpret_cast<const float4 *>(desc1 + (size_t)(ok0 ? q0i : 0) * K);
+        const float4 *r1 = reinterpret_cast<const float4 *>(desc1 + (size_t)(ok1 ? q1i : 0) * K);
+#pragma unroll
+        for (int v = 0; v < 32; ++v) {
+            const float4 f0 = r0[v], f1 = r1[v];
+            qa[2 * v] = ok0 ? (half ? f0.y : f0.x) : 0.f;
+            qa[2 * v + 1] = ok0 ? (half ? f0.w : f0.z) : 0.f;
+            qb[2 * v] = ok1 ? (half ? f1.y : f1.x) : 0.f;
+            qb[2 * v + 1] = ok1 ? (half ? f1.w : f1.z) : 0.f;
+        }
+    }
+    const float na0 = q0i < n1 ? qnorm[q0i] : 0.f;
+    const float na1 = q1i < n1 ? qnorm[q1i] : 0.f;
+    const bool live0 = q0i < n1, live1 = q1i < n1;
+    float m0 = __builtin_inff(), m1 = __builtin_inff();  // running min of (d~ + eps)
+
+    const int t_begin = blockIdx.y * tiles_per_seg;
+    const int t_end = min(t_begin + tiles_per_seg, tiles_total);
+    if (t_begin >= t_end) return;
+
+    // Tile staging: 32 KiB = 32 wave-instructions of global_load_lds_dwordx4 (1 KiB each,
+    // LDS destination = wave-uniform base + lane*16, no VGPRs).  The loads of tile t+1 are
+    // issued before the MFMAs of tile t and retire at the barrier that ends the iteration.
+    auto stage = [&](int t, int buf) {
+        const float *src = frag + (size_t)t * MF_TJ * MF_BLOCK_FLOATS;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int chunk = (k * MF_WAVES + wave) * 256;  // floats; 64 lanes x 4 floats per chunk
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + chunk + 4 * lane),
+                (__attribute__((address_space(3))) void *)(&tile[buf][chunk]), 16, 0, 0);
+        }
+    };
+
+    stage(t_begin, 0);
+    __syncthreads();
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        if (t + 1 < t_end) stage(t + 1, buf ^ 1);
+
+        for (int jb = 0; jb < MF_TJ; ++jb) {
+            const float4 *bf = reinterpret_cast<const float4 *>(tile[buf] + jb * MF_BLOCK_FLOATS) + lane;
+            f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float4 b = bf[g * 64];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, qa[4 * g + 0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, qb[4 * g + 0], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, qa[4 * g + 1], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, qb[4 * g + 1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, qa[4 * g + 2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, qb[4 * g + 2], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, qa[4 * g + 3], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, qb[4 * g + 3], acc1, 0, 0, 0);
+            }
+            // epilogue: this lane holds, for its two queries, rows
+            //   j = j0 + (r&3) + 8*(r>>2) + 4*half, r = 0..15 (ascending in r)
+            const int j0 = (t * MF_TJ + jb) * MF_JB;
+            const float4 *nb4 = reinterpret_cast<const float4 *>(bnorm + j0 + 4 * half);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 nb = nb4[2 * q];  // rows j0 + 8q + 4half + 0..3
+                const float nbv[4] = {nb.x, nb.y, nb.z, nb.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * q + e;
+                    const int j = j0 + 8 * q + 4 * half + e;
+                    {
+                        const float s = na0 + nbv[e];
+                        const float d = fmaf(-2.0f, acc0[r], s);
+                        const float eps = fmaf(MF_C, s, MF_TINY);
+                        if (!(d - eps > m0) && live0 && j < n2) {
+                            const int pos = atomicAdd(cand_count + q0i, 1);
+                            if (pos < MF_CAP) cand[(size_t)q0i * MF_CAP + pos] = j;
+                        }
+                        m0 = fminf(m0, d + eps);
+                    }
+                    {
+                        const float s = na1 + nbv[e];
+                        const float d = fmaf(-2.0f, acc1[r], s);
+                        const float eps = fmaf(MF_C, s, MF_TINY);
+                        if (!(d - eps > m1) && live1 && j < n2) {
+                            const int pos = atomicAdd(cand_count + q1i, 1);
+                            if (pos < MF_CAP) cand[(size_t)q1i * MF_CAP + pos] = j;
+                        }
+                        m1 = fminf(m1, d + eps);
+                    }
+                }
+            }
+            // the two half-waves see disjoint rows of the same queries: share the bound
+            m0 = fminf(m0, __shfl_xor(m0, 32));
+            m1 = fminf(m1, __shfl_xor(m1, 32));
+        }
+
+        __syncthreads();
+    }
+}
+
+// Phase 2: one wave per query.
+__global__ __launch_bounds__(64) void match_replay_kernel(
+    const float *__restrict__ desc1, const float *__restrict__ score1, int n1,
+    const float *__restrict__ desc2, const float *__restrict__ score2, int n2, float dist_limit,
+    const int *__restrict__ cand_count, const int *__restrict__ cand, int *__restrict__ overflow_count,
+    int *__restrict__ overflow_list, int32_t *__restrict__ closest_out, int32_t *__restrict__ second_out,
+    float *__restrict__ min_dist_out, float *__restrict__ second_dist_out, uint8_t *__restrict__ status_out)
+{
+    __shared__ int cj[MF_CAP];
+    __shared__ int sj[MF_CAP];
+    __shared__ float dist[MF_CAP];
+    __shared__ float q[K];
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int count = cand_count[i];
+    if (count > MF_CAP) {  // too many near-ties: exact scan for this query
+        if (lane == 0) overflow_list[atomicAdd(overflow_count, 1)] = i;
+        return;
+    }
+    for (int p = lane; p < count; p += 64) cj[p] = cand[(size_t)i * MF_CAP + p];
+    q[lane] = desc1[(size_t)i * K + lane];
+    q[lane + 64] = desc1[(size_t)i * K + lane + 64];
+    __syncthreads();
+    // rank sort (candidate indices are distinct)
+#pragma unroll 1
+    for (int p = lane; p < count; p += 64) {
+        const int j = cj[p];
+        int rank = 0;
+#pragma unroll 4
+        for (int o = 0; o < count; ++o) rank += cj[o] < j;
+        sj[rank] = j;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int p = lane; p < count; p += 64) {
+        const float4 *b = reinterpret_cast<const float4 *>(desc2 + (size_t)sj[p] * K);
+        float norm = 0.0f;
+#pragma unroll 4
+        for (int k4 = 0; k4 < K / 4; ++k4) {  // reference order: k ascending, one accumulator
+            const float4 bv = b[k4];
+            float d;
+            d = q[4 * k4 + 0] - bv.x; norm = norm + d * d;
+            d = q[4 * k4 + 1] - bv.y; norm = norm + d * d;
+            d = q[4 * k4 + 2] - bv.z; norm = norm + d * d;
+            d = q[4 * k4 + 3] - bv.w; norm = norm + d * d;
+        }
+        dist[p] = sqrtf(norm);
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    int closest = -1, second = -1;
+    float min_dist = -1.0f, second_dist = -1.0f;
+    if (count > 0) {  // sj[0] is list2[0]: taken unconditionally (minDist == -1, Features.cpp:1041)
+        closest = sj[0];
+        min_dist = dist[0];
+#pragma unroll 1
+        for (int p = 1; p < count; ++p) {
+            if (dist[p] < min_dist) {
+                second = closest;
+                second_dist = min_dist;
+                closest = sj[p];
+                min_dist = dist[p];
+            }
+        }
+    }
+    if (closest_out) closest_out[i] = closest;
+    if (second_out) second_out[i] = second;
+    if (min_dist_out) min_dist_out[i] = min_dist;
+    if (second_dist_out) second_dist_out[i] = second_dist;
+    if (status_out)
+        status_out[i] = match_status(closest, second, min_dist, second_dist, score1[i], score2, dist_limit);
+}
+
 }  // namespace
+
+static int launch_exact(stx_ctx *ctx, const float *d_desc1, const float *d_score1, int n1,
+                        const float *d_desc2, const float *d_score2, int n2, float dist_limit,
+                        const int32_t *query_list, const int *n_queries_dev, int32_t *d_closest,
+                        int32_t *d_second, float *d_min_dist, float *d_second_dist, uint8_t *d_status)
+{
+    const int blocks = (n1 + EXACT_THREADS - 1) / EXACT_THREADS;
+    hipLaunchKernelGGL(match_exact_kernel, dim3(blocks), dim3(EXACT_THREADS), 0, ctx->stream, d_desc1,
+                       d_score1, n1, d_desc2, d_score2, n2, dist_limit, query_list, n_queries_dev, n1,
+                       d_closest, d_second, d_min_dist, d_second_dist, d_status);
+    return (int)hipGetLastError();
+}
 
 int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, int n1,
                      const float *d_desc2, const float *d_score2, int n2, float dist_limit,
@@ -121,10 +404,57 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
                      float *d_second_dist, uint8_t *d_status)
 {
     if (n1 <= 0) return STX_OK;
-    const int blocks = (n1 + EXACT_THREADS - 1) / EXACT_THREADS;
-    hipLaunchKernelGGL(match_exact_kernel, dim3(blocks), dim3(EXACT_THREADS), 0, ctx->stream,
-                       d_desc1, d_score1, n1, d_desc2, d_score2, n2, dist_limit,
-                       (const int32_t *)nullptr, n1, d_closest, d_second, d_min_dist,
+    int algo = ctx->match_algo;
+    if (algo == STX_MATCH_AUTO)
+        algo = ((double)n1 * (double)n2 >= 4.0e6 && n2 >= 1024) ? STX_MATCH_MFMA : STX_MATCH_EXACT;
+    if (algo == STX_MATCH_EXACT || n2 == 0)
+        return launch_exact(ctx, d_desc1, d_score1, n1, d_desc2, d_score2, n2, dist_limit, nullptr,
+                            nullptr, d_closest, d_second, d_min_dist, d_second_dist, d_status);
+
+    // ---- MFMA prefilter + replay ------------------------------------------
+    const int n2pad = (n2 + MF_TILE_ROWS - 1) / MF_TILE_ROWS * MF_TILE_ROWS;
+    const int tiles_total = n2pad / MF_TILE_ROWS;
+    const int qblocks = (n1 + MF_QB - 1) / MF_QB;
+    // segments of list2: fill the CUs evenly (2 workgroups per CU), keep segments long
+    const int slots = 2 * (ctx->num_cus > 0 ? ctx->num_cus : 256);
+    int segs = 1;
+    double best_eff = 0;
+    for (int s = 1; s <= 6; ++s) {
+        if (s > 1 && tiles_total / s < 16) break;
+        const long wgs = (long)qblocks * s;
+        const double eff = (double)wgs / (double)(((wgs + slots - 1) / slots) * slots);
+        if (eff > best_eff + 0.02) { best_eff = eff; segs = s; }
+    }
+    const int tiles_per_seg = (tiles_total + segs - 1) / segs;
+    segs = (tiles_total + tiles_per_seg - 1) / tiles_per_seg;
+
+    int err;
+    float *frag = (float *)stx_workspace(ctx, STX_SLOT_M_FRAG, sizeof(float) * ((size_t)n2pad * K + n2pad), &err);
+    if (!frag) return err;
+    float *bnorm = frag + (size_t)n2pad * K;
+    float *qnorm = (float *)stx_workspace(ctx, STX_SLOT_M_QNORM, sizeof(float) * (size_t)n1, &err);
+    if (!qnorm) return err;
+    // [count n1][overflow_count 1 (+pad)][overflow_list n1][cand n1*CAP]
+    const size_t n1a = ((size_t)n1 + 3) & ~(size_t)3;
+    int *cnt = (int *)stx_workspace(ctx, STX_SLOT_M_CAND, sizeof(int) * (n1a + 4 + n1a + (size_t)n1 * MF_CAP), &err);
+    if (!cnt) return err;
+    int *ovf_count = cnt + n1a;
+    int *ovf_list = ovf_count + 4;
+    int *cand = ovf_list + n1a;
+    hipStream_t st = ctx->stream;
+    STX_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (n1a + 4), st));
+    hipLaunchKernelGGL(match_prep_frag_kernel, dim3((unsigned)(((size_t)n2pad * K / 4 + 255) / 256)), dim3(256),
+                       0, st, d_desc2, n2, n2pad, frag);
+    hipLaunchKernelGGL(match_norm_kernel, dim3((n2pad + 255) / 256), dim3(256), 0, st, d_desc2, n2, n2pad, bnorm);
+    hipLaunchKernelGGL(match_norm_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_desc1, n1, n1, qnorm);
+    hipLaunchKernelGGL(match_mfma_kernel, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm, n1,
+                       frag, bnorm, n2, tiles_total, tiles_per_seg, cnt, cand);
+    hipLaunchKernelGGL(match_replay_kernel, dim3(n1), dim3(64), 0, st, d_desc1, d_score1, n1, d_desc2, d_score2,
+                       n2, dist_limit, cnt, cand, ovf_count, ovf_list, d_closest, d_second, d_min_dist,
                        d_second_dist, d_status);
-    return (int)hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    // queries whose candidate list overflowed (count read on the device)
+    return launch_exact(ctx, d_desc1, d_score1, n1, d_desc2, d_score2, n2, dist_limit, ovf_list, ovf_count,
+                        d_closest, d_second, d_min_dist, d_second_dist, d_status);
 }
