@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary kernels")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--match-n", type=int, default=32768, help="n1 = n2 of the matching leg")
+    ap.add_argument("--match-n", type=int, default=200000, help="n1 = n2 of the matching leg (BASELINE config 5)")
     args = ap.parse_args()
 
     import torch
@@ -156,7 +156,10 @@ def main():
         "peak": VALU_LANEOPS / 1e12,
         "unit": "Tlane-op/s",
         "frac": achieved / VALU_LANEOPS,
-        "traffic": None,
+        # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc_disp_band_kernel.md):
+        # FETCH_SIZE 12.22 MB (raw, byte loads) + WRITE_SIZE 6.15 MB; algorithmic 3 B/pixel = 17.2 MB
+        "traffic": 18.37e6,
+        "algorithmic_bytes": 3.0 * W * H,
         "model": "%d integer lane-ops per (pixel,candidate) unit (SURVEY 8d); peak = %d CU x 64 lanes/clk "
                  "x %.1f GHz" % (OPS_PER_UNIT_WINDOWED, CUS, CLOCK_HZ / 1e9),
         "kernel_ms": kernel_ms,
@@ -213,7 +216,7 @@ def main():
         ms = event_time_ms(torch, lambda: ctx.match_dev(td1, ts1, td2, ts2, 1000.0, oc, os_, om, od, ot), 2, 1)
         flops = 2.0 * n * n * 128
         extra["match"] = {
-            "workload": "%d x %d 128-d fp32 SIFT-like descriptors (BASELINE config 5 shape, scaled)" % (n, n),
+            "workload": "BASELINE config 5: %d x %d 128-d fp32 SIFT-like descriptors, fp32 MFMA prefilter + exact replay" % (n, n),
             "ms": ms, "matched_descriptors_per_s": n / (ms * 1e-3),
             "pair_evaluations_per_s": float(n) * n / (ms * 1e-3),
             "accepted": int((ot == 3).sum().item()),
