@@ -206,6 +206,68 @@ def test_disparity_full_size_properties(ctx, oracle):
         assert (gw[y0:y0 + 5] == want[off:off + 5]).all()
 
 
+def _check_rows_against_oracle(got, l, r, win, D, rows, dtype=np.uint8):
+    """The scan needs only rows y-win//2 .. y+win//2: run the oracle on small bands."""
+    h = l.shape[0]
+    rr = win // 2
+    for y0 in rows:
+        b0, b1 = max(0, y0 - rr), min(h, y0 + 4 + rr)
+        want = oracle_mod.disparity_ext(l[b0:b1], r[b0:b1], win, D, 0, dtype, sliding=True)
+        # band rows whose window is inside the band, or clipped by the true image edge
+        lo = y0 - b0
+        assert (got[y0:y0 + 4] == want[lo:lo + 4]).all(), "rows %d.." % y0
+
+
+def test_config3_4k_512_disparities_rowbands(ctx, oracle):
+    """BASELINE config 3: 3840x2160, 512 disparities (two 256-disparity passes, u16 output),
+    single call vs. 4 row bands with halo, oracle on sampled rows."""
+    import torch
+    from stereo_amd.dist import row_band
+    global oracle_mod
+    oracle_mod = oracle
+    h, w, D, win = 2160, 3840, 512, 9
+    l, r = synth.rectified_pair(303, h, w, D)
+    full = ctx.disparity(l, r, win=win, max_disp=D, out_dtype=np.uint16)
+    assert full.max() > 255
+    _check_rows_against_oracle(full, l, r, win, D, [0, 1077, h - 4], np.uint16)
+    a, b = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
+    out = torch.zeros(h, w, dtype=torch.int16, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        for rank in range(4):
+            row0, rows, b0, bh = row_band(h, rank, 4, win // 2)
+            ctx.disparity_rowband_dev(a[b0:b0 + bh], b[b0:b0 + bh], b0, h, row0, rows,
+                                      out[row0:row0 + rows], win=win, max_disp=D)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_stream(0)
+    assert (out.cpu().numpy().view(np.uint16) == full).all()
+
+
+def test_config4_batch_1080p_192_disparities(ctx, oracle):
+    """BASELINE config 4 shape (a 4-pair slice of the 1024-pair batch): batched device
+    call equals per-pair calls; oracle on sampled rows."""
+    import torch
+    global oracle_mod
+    oracle_mod = oracle
+    h, w, D, win, n = 1080, 1920, 192, 9, 4
+    pairs = [synth.rectified_pair(400 + k, h, w, D) for k in range(n)]
+    a = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
+    b = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    out = torch.empty_like(a)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.disparity_dev(a, b, out, win=win, max_disp=D)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_stream(0)
+    got = out.cpu().numpy()
+    for k in (0, n - 1):
+        _check_rows_against_oracle(got[k], pairs[k][0], pairs[k][1], win, D, [0, 500, h - 4])
+    single = ctx.disparity(pairs[1][0], pairs[1][1], win=win, max_disp=D)
+    assert (got[1] == single).all()
+
+
 # ------------------------------------------------------------------ R ------
 
 def _rect_case(seed, h, w, deg=2.0):
