@@ -61,9 +61,10 @@ extern "C" {
                                    misses are written as 0 and dst is never read */
 
 /* matching algorithm selector (stx_set_match_algo) */
-#define STX_MATCH_AUTO 0  /* exact scan for small problems, MFMA prefilter otherwise */
+#define STX_MATCH_AUTO 0  /* exact scan for small problems, bf16x3 MFMA prefilter otherwise */
 #define STX_MATCH_EXACT 1 /* VALU scan in reference operation order */
 #define STX_MATCH_MFMA 2  /* fp32 MFMA prefilter + exact replay of the running-minimum records */
+#define STX_MATCH_MFMA_BF16 3 /* same with the dot products as 3 bf16 MFMA products (hi/lo split) */
 
 /* disparity kernel selector (stx_set_disparity_algo) */
 #define STX_DISP_AUTO 0       /* sliding-sum kernel where it applies (SAD, win <= 9), else tap-by-tap */
@@ -182,6 +183,17 @@ int stx_disparity_rowband_dev(stx_ctx *ctx, const uint8_t *d_img0,
                               int full_h, size_t stride, int row0, int rows, int win,
                               int max_disp, int cost_mode, void *d_out,
                               size_t out_stride, int out_bytes);
+
+/* ---- R+D fused on the device ---------------------------------------------
+ * main.cpp:362-380 in one call: both images are rectified into zero-initialised
+ * destinations of the source size (RectifyImage twice, Stereography.cpp:596-631) and the
+ * disparity scan (ComputeDepthImage, :649-691, or D1-ext) runs on the rectified pair
+ * without leaving the GPU.  Hinv0/Hinv1 are inverse homographies as for stx_rectify_u8.
+ * rect0/rect1 (optional, may be NULL) receive the rectified images.  Host pointers. */
+int stx_rectify_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int w, int h,
+                             size_t stride, const float Hinv0[9], const float Hinv1[9], int win,
+                             int max_disp, int cost_mode, uint8_t *out, size_t out_stride,
+                             uint8_t *rect0, uint8_t *rect1, size_t rect_stride);
 
 #ifdef __cplusplus
 }

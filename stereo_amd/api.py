@@ -29,7 +29,7 @@ DESC_LENGTH = 128
 MATCH_FAILED, MATCH_SCORE, MATCH_RATIO, MATCH_ACCEPTED = 0, 1, 2, 3
 COST_SAD, COST_SSD = 0, 1
 RECT_PRESERVE_DST, RECT_DST_IS_ZERO = 0, 1
-MATCH_AUTO, MATCH_EXACT, MATCH_MFMA = 0, 1, 2
+MATCH_AUTO, MATCH_EXACT, MATCH_MFMA, MATCH_MFMA_BF16 = 0, 1, 2, 3
 DISP_AUTO, DISP_BRUTEFORCE = 0, 1
 
 
@@ -168,6 +168,29 @@ class Context:
         check(fn(self._h, _ptr(img0), _ptr(img1), w, h, stride, int(win), int(max_disp),
                  int(cost_mode), _ptr(out), max(w, 1) * out_dtype.itemsize), "stx_disparity")
         return out
+
+    def rectify_disparity(self, img0, img1, Hinv0, Hinv1, win=1, max_disp=0, cost_mode=COST_SAD,
+                          want_rectified=False):
+        """main.cpp:362-380 on the device: rectify both images into zeroed destinations,
+        then scan.  Returns depth, or (depth, rect0, rect1)."""
+        _check_image(img0, "img0")
+        _check_image(img1, "img1")
+        if img0.shape != img1.shape:
+            raise ValueError("img0 and img1 must have the same shape")
+        img0, img1 = np.ascontiguousarray(img0), np.ascontiguousarray(img1)
+        h, w = img0.shape
+        out = np.zeros((h, w), np.uint8)
+        r0 = np.zeros((h, w), np.uint8) if want_rectified else None
+        r1 = np.zeros((h, w), np.uint8) if want_rectified else None
+        fp = C.POINTER(C.c_float)
+        h0 = np.ascontiguousarray(Hinv0, np.float32).reshape(9)
+        h1 = np.ascontiguousarray(Hinv1, np.float32).reshape(9)
+        check(self._lib.stx_rectify_disparity_u8(
+            self._h, _ptr(img0), _ptr(img1), w, h, max(w, 1), h0.ctypes.data_as(fp),
+            h1.ctypes.data_as(fp), int(win), int(max_disp), int(cost_mode), _ptr(out), max(w, 1),
+            _ptr(r0) if want_rectified else None, _ptr(r1) if want_rectified else None, max(w, 1)),
+            "stx_rectify_disparity_u8")
+        return (out, r0, r1) if want_rectified else out
 
     def disparity_dev(self, img0, img1, out, win=1, max_disp=0, cost_mode=COST_SAD):
         """img0/img1: [n,H,W] or [H,W] uint8 device tensors; out: same shape, uint8 or int16."""

@@ -152,6 +152,50 @@ constexpr int MF_CAP = 256;            // candidate slots per query
 constexpr float MF_C = 6.103515625e-05f;  // 2^-14 >= 523 * 2^-24
 constexpr float MF_TINY = 1e-37f;      // covers underflow in either computation
 
+
+// Epilogue shared by both prefilter kernels.  After an MFMA row block this lane holds, for
+// its two queries (column blocks 0/1), the dot products with rows
+//   j = j0 + (r&3) + 8*(r>>2) + 4*half, r = 0..15 (ascending in r),
+// tests each against the running bound and appends survivors to the query's list.
+__device__ __forceinline__ void prefilter_epilogue(const f32x16 &acc0, const f32x16 &acc1, int j0, int half,
+                                                   const float *__restrict__ bnorm, int n2, float na0,
+                                                   float na1, bool live0, bool live1, int q0i, int q1i,
+                                                   float c, float &m0, float &m1,
+                                                   int *__restrict__ cand_count, int *__restrict__ cand)
+{
+    const float4 *nb4 = reinterpret_cast<const float4 *>(bnorm + j0 + 4 * half);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 nb = nb4[2 * q];  // rows j0 + 8q + 4half + 0..3
+        const float nbv[4] = {nb.x, nb.y, nb.z, nb.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e;
+            const int j = j0 + 8 * q + 4 * half + e;
+            {
+                const float s = na0 + nbv[e];
+                const float d = fmaf(-2.0f, acc0[r], s);
+                const float eps = fmaf(c, s, MF_TINY);
+                if (!(d - eps > m0) && live0 && j < n2) {
+                    const int pos = atomicAdd(cand_count + q0i, 1);
+                    if (pos < MF_CAP) cand[(size_t)q0i * MF_CAP + pos] = j;
+                }
+                m0 = fminf(m0, d + eps);
+            }
+            {
+                const float s = na1 + nbv[e];
+                const float d = fmaf(-2.0f, acc1[r], s);
+                const float eps = fmaf(c, s, MF_TINY);
+                if (!(d - eps > m1) && live1 && j < n2) {
+                    const int pos = atomicAdd(cand_count + q1i, 1);
+                    if (pos < MF_CAP) cand[(size_t)q1i * MF_CAP + pos] = j;
+                }
+                m1 = fminf(m1, d + eps);
+            }
+        }
+    }
+}
+
 // list2 -> MFMA A-operand fragment order, rows padded with zeros to n2pad:
 //   frag[((jb*16 + g)*64 + lane)*4 + t] = desc2[jb*32 + (lane&31)][2*(4g+t) + (lane>>5)]
 __global__ __launch_bounds__(256) void match_prep_frag_kernel(const float *__restrict__ desc2, int n2,
@@ -268,45 +312,154 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_kernel(
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, qa[4 * g + 3], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, qb[4 * g + 3], acc1, 0, 0, 0);
             }
-            // epilogue: this lane holds, for its two queries, rows
-            //   j = j0 + (r&3) + 8*(r>>2) + 4*half, r = 0..15 (ascending in r)
-            const int j0 = (t * MF_TJ + jb) * MF_JB;
-            const float4 *nb4 = reinterpret_cast<const float4 *>(bnorm + j0 + 4 * half);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 nb = nb4[2 * q];  // rows j0 + 8q + 4half + 0..3
-                const float nbv[4] = {nb.x, nb.y, nb.z, nb.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * q + e;
-                    const int j = j0 + 8 * q + 4 * half + e;
-                    {
-                        const float s = na0 + nbv[e];
-                        const float d = fmaf(-2.0f, acc0[r], s);
-                        const float eps = fmaf(MF_C, s, MF_TINY);
-                        if (!(d - eps > m0) && live0 && j < n2) {
-                            const int pos = atomicAdd(cand_count + q0i, 1);
-                            if (pos < MF_CAP) cand[(size_t)q0i * MF_CAP + pos] = j;
-                        }
-                        m0 = fminf(m0, d + eps);
-                    }
-                    {
-                        const float s = na1 + nbv[e];
-                        const float d = fmaf(-2.0f, acc1[r], s);
-                        const float eps = fmaf(MF_C, s, MF_TINY);
-                        if (!(d - eps > m1) && live1 && j < n2) {
-                            const int pos = atomicAdd(cand_count + q1i, 1);
-                            if (pos < MF_CAP) cand[(size_t)q1i * MF_CAP + pos] = j;
-                        }
-                        m1 = fminf(m1, d + eps);
-                    }
-                }
-            }
+            prefilter_epilogue(acc0, acc1, (t * MF_TJ + jb) * MF_JB, half, bnorm, n2, na0, na1, live0, live1,
+                               q0i, q1i, MF_C, m0, m1, cand_count, cand);
             // the two half-waves see disjoint rows of the same queries: share the bound
             m0 = fminf(m0, __shfl_xor(m0, 32));
             m1 = fminf(m1, __shfl_xor(m1, 32));
         }
 
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// bf16 x 3 variant of the prefilter.  Every fp32 value is split a = hi + lo + r with
+// hi = bf16(a), lo = bf16(a - hi), |r| <= 2^-18 |a|, and the dot product is taken as
+// hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate, 3 products =
+// 5.3x fewer matrix cycles).  The extra error (dropped lo.lo and residual terms
+// <= 3*2^-18 sum|a||b|, 384 fp32 accumulations) is covered by the wider bound MF_C_BF16
+// (DESIGN.md); everything downstream -- candidate lists, exact replay -- is unchanged, so the
+// outputs stay bit-identical to the reference.
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr float MF_C_BF16 = 1.220703125e-04f;  // 2^-13
+
+__device__ __forceinline__ unsigned bf16_rne(float a)
+{
+    unsigned u = __float_as_uint(a);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0u;  // NaN stays NaN
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void bf16_split(float a, unsigned &hi, unsigned &lo)
+{
+    hi = bf16_rne(a);
+    lo = bf16_rne(a - __uint_as_float(hi << 16));
+}
+// 8 consecutive floats -> packed hi (8 x bf16) and lo (8 x bf16)
+__device__ __forceinline__ void bf16_split8(const float4 &x, const float4 &y, uint4 &hi, uint4 &lo)
+{
+    const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bf16_split(v[i], h[i], l[i]);
+    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
+// list2 -> A-operand fragment order of v_mfma_f32_32x32x16_bf16 (lane holds
+// A[row = lane&31][k = 16s + 8*(lane>>5) + 0..7]):
+//   frag16[((jb*8 + s)*2 + part)*64 + lane]  (uint4 = 8 bf16), part 0 = hi, 1 = lo
+__global__ __launch_bounds__(256) void match_prep_frag_bf16_kernel(const float *__restrict__ desc2, int n2,
+                                                                   int n2pad, uint4 *__restrict__ frag16)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // one (jb, s, lane)
+    const size_t total = (size_t)n2pad / MF_JB * 8 * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int s = (int)((idx >> 6) & 7);
+    const size_t jb = idx >> 9;
+    const size_t j = jb * MF_JB + (lane & 31);
+    uint4 hi = make_uint4(0, 0, 0, 0), lo = hi;
+    if (j < (size_t)n2) {
+        const float4 *row = reinterpret_cast<const float4 *>(desc2 + j * K + 16 * s + 8 * (lane >> 5));
+        bf16_split8(row[0], row[1], hi, lo);
+    }
+    uint4 *dst = frag16 + ((jb * 8 + s) * 2) * 64 + lane;
+    dst[0] = hi;
+    dst[64] = lo;
+}
+
+__global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16_kernel(
+    const float *__restrict__ desc1, const float *__restrict__ qnorm, int n1,
+    const uint4 *__restrict__ frag16, const float *__restrict__ bnorm, int n2, int tiles_total,
+    int tiles_per_seg, int *__restrict__ cand_count, int *__restrict__ cand)
+{
+    // one row block = 8 k-steps x {hi, lo} x 64 lanes x 16 B = 16 KiB; tile = MF_TJ row blocks
+    __shared__ uint4 tile[2][MF_TJ * 1024];  // 64 KiB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const int q0i = blockIdx.x * MF_QB + wave * MF_QW + col;
+    const int q1i = q0i + 32;
+    const bool live0 = q0i < n1, live1 = q1i < n1;
+
+    // query fragments: B operand, lane holds q[i][16s + 8*half + 0..7] as hi and lo
+    bf16x8 qh0[8], ql0[8], qh1[8], ql1[8];
+    {
+        const float4 *r0 = reinterpret_cast<const float4 *>(desc1 + (size_t)(live0 ? q0i : 0) * K + 8 * half);
+        const float4 *r1 = reinterpret_cast<const float4 *>(desc1 + (size_t)(live1 ? q1i : 0) * K + 8 * half);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            uint4 h, l;
+            bf16_split8(r0[4 * s], r0[4 * s + 1], h, l);
+            if (!live0) h = l = make_uint4(0, 0, 0, 0);
+            qh0[s] = __builtin_bit_cast(bf16x8, h);
+            ql0[s] = __builtin_bit_cast(bf16x8, l);
+            bf16_split8(r1[4 * s], r1[4 * s + 1], h, l);
+            if (!live1) h = l = make_uint4(0, 0, 0, 0);
+            qh1[s] = __builtin_bit_cast(bf16x8, h);
+            ql1[s] = __builtin_bit_cast(bf16x8, l);
+        }
+    }
+    const float na0 = live0 ? qnorm[q0i] : 0.f;
+    const float na1 = live1 ? qnorm[q1i] : 0.f;
+    float m0 = __builtin_inff(), m1 = __builtin_inff();
+
+    const int t_begin = blockIdx.y * tiles_per_seg;
+    const int t_end = min(t_begin + tiles_per_seg, tiles_total);
+    if (t_begin >= t_end) return;
+
+    auto stage = [&](int t, int buf) {
+        const uint4 *src = frag16 + (size_t)t * MF_TJ * 1024;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int chunk = (k * MF_WAVES + wave) * 64;  // uint4 units, 1 KiB per wave-instruction
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + chunk + lane),
+                (__attribute__((address_space(3))) void *)(&tile[buf][chunk]), 16, 0, 0);
+        }
+    };
+
+    stage(t_begin, 0);
+    __syncthreads();
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        if (t + 1 < t_end) stage(t + 1, buf ^ 1);
+
+        for (int jb = 0; jb < MF_TJ; ++jb) {
+            const uint4 *bf = tile[buf] + jb * 1024 + lane;
+            f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, bf[(2 * s) * 64]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, bf[(2 * s + 1) * 64]);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, qh0[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, qh1[s], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ql0[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ql1[s], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, qh0[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, qh1[s], acc1, 0, 0, 0);
+            }
+            prefilter_epilogue(acc0, acc1, (t * MF_TJ + jb) * MF_JB, half, bnorm, n2, na0, na1, live0, live1,
+                               q0i, q1i, MF_C_BF16, m0, m1, cand_count, cand);
+            m0 = fminf(m0, __shfl_xor(m0, 32));
+            m1 = fminf(m1, __shfl_xor(m1, 32));
+        }
         __syncthreads();
     }
 }
@@ -406,7 +559,7 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     if (n1 <= 0) return STX_OK;
     int algo = ctx->match_algo;
     if (algo == STX_MATCH_AUTO)
-        algo = ((double)n1 * (double)n2 >= 4.0e6 && n2 >= 1024) ? STX_MATCH_MFMA : STX_MATCH_EXACT;
+        algo = ((double)n1 * (double)n2 >= 4.0e6 && n2 >= 1024) ? STX_MATCH_MFMA_BF16 : STX_MATCH_EXACT;
     if (algo == STX_MATCH_EXACT || n2 == 0)
         return launch_exact(ctx, d_desc1, d_score1, n1, d_desc2, d_score2, n2, dist_limit, nullptr,
                             nullptr, d_closest, d_second, d_min_dist, d_second_dist, d_status);
@@ -443,12 +596,22 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     int *cand = ovf_list + n1a;
     hipStream_t st = ctx->stream;
     STX_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (n1a + 4), st));
-    hipLaunchKernelGGL(match_prep_frag_kernel, dim3((unsigned)(((size_t)n2pad * K / 4 + 255) / 256)), dim3(256),
-                       0, st, d_desc2, n2, n2pad, frag);
+    const bool bf16 = algo == STX_MATCH_MFMA_BF16;
+    if (bf16)
+        hipLaunchKernelGGL(match_prep_frag_bf16_kernel, dim3((unsigned)(((size_t)n2pad / MF_JB * 512 + 255) / 256)),
+                           dim3(256), 0, st, d_desc2, n2, n2pad, reinterpret_cast<uint4 *>(frag));
+    else
+        hipLaunchKernelGGL(match_prep_frag_kernel, dim3((unsigned)(((size_t)n2pad * K / 4 + 255) / 256)), dim3(256),
+                           0, st, d_desc2, n2, n2pad, frag);
     hipLaunchKernelGGL(match_norm_kernel, dim3((n2pad + 255) / 256), dim3(256), 0, st, d_desc2, n2, n2pad, bnorm);
     hipLaunchKernelGGL(match_norm_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_desc1, n1, n1, qnorm);
-    hipLaunchKernelGGL(match_mfma_kernel, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm, n1,
-                       frag, bnorm, n2, tiles_total, tiles_per_seg, cnt, cand);
+    if (bf16)
+        hipLaunchKernelGGL(match_mfma_bf16_kernel, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm,
+                           n1, reinterpret_cast<const uint4 *>(frag), bnorm, n2, tiles_total, tiles_per_seg, cnt,
+                           cand);
+    else
+        hipLaunchKernelGGL(match_mfma_kernel, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm, n1,
+                           frag, bnorm, n2, tiles_total, tiles_per_seg, cnt, cand);
     hipLaunchKernelGGL(match_replay_kernel, dim3(n1), dim3(64), 0, st, d_desc1, d_score1, n1, d_desc2, d_score2,
                        n2, dist_limit, cnt, cand, ovf_count, ovf_list, d_closest, d_second, d_min_dist,
                        d_second_dist, d_status);

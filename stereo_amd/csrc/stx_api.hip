@@ -85,7 +85,8 @@ extern "C" int stx_synchronize(stx_ctx *ctx)
 extern "C" int stx_set_match_algo(stx_ctx *ctx, int algo)
 {
     if (!ctx) return STX_ERR_INVALID_ARG;
-    if (algo != STX_MATCH_AUTO && algo != STX_MATCH_EXACT && algo != STX_MATCH_MFMA)
+    if (algo != STX_MATCH_AUTO && algo != STX_MATCH_EXACT && algo != STX_MATCH_MFMA &&
+        algo != STX_MATCH_MFMA_BF16)
         return STX_ERR_INVALID_ARG;
     ctx->match_algo = algo;
     return STX_OK;
@@ -377,4 +378,49 @@ extern "C" int stx_disparity_u16(stx_ctx *ctx, const uint8_t *img0, const uint8_
                                  uint16_t *out, size_t out_stride)
 {
     return disparity_host(ctx, img0, img1, w, h, stride, win, max_disp, cost_mode, out, out_stride, 2);
+}
+
+// ------------------------------------------------------------- R + D fused --
+
+extern "C" int stx_rectify_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int w,
+                                        int h, size_t stride, const float Hinv0[9], const float Hinv1[9],
+                                        int win, int max_disp, int cost_mode, uint8_t *out,
+                                        size_t out_stride, uint8_t *rect0, uint8_t *rect1,
+                                        size_t rect_stride)
+{
+    if (!ctx || !Hinv0 || !Hinv1) return STX_ERR_INVALID_ARG;
+    int rc = check_disparity_args(w, h, stride, win, max_disp, cost_mode, 1, out_stride);
+    if (rc) return rc;
+    if ((rect0 || rect1) && rect_stride < (size_t)w) return STX_ERR_INVALID_ARG;
+    if (w == 0 || h == 0) return STX_OK;
+    if (!img0 || !img1 || !out) return STX_ERR_INVALID_ARG;
+    STX_HIP(hipSetDevice(ctx->device));
+    int err;
+    hipStream_t s = ctx->stream;
+    const size_t p = ((size_t)w + 15) & ~(size_t)15;
+    const size_t img = p * (size_t)h;
+    // [src0 | src1] in IMG0, [rect0 | rect1] in IMG1, disparity in OUT
+    uint8_t *dsrc = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG0, 2 * img, &err);
+    if (!dsrc) return err;
+    uint8_t *drect = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG1, 2 * img, &err);
+    if (!drect) return err;
+    uint8_t *dout = (uint8_t *)stx_workspace(ctx, STX_SLOT_OUT, img, &err);
+    if (!dout) return err;
+    STX_HIP(hipMemcpy2DAsync(dsrc, p, img0, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, s));
+    STX_HIP(hipMemcpy2DAsync(dsrc + img, p, img1, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, s));
+    float hinv[18];
+    memcpy(hinv, Hinv0, 9 * sizeof(float));
+    memcpy(hinv + 9, Hinv1, 9 * sizeof(float));
+    // zero-initialised destinations (Mat::zeros, main.cpp:362,366): misses are written as 0
+    rc = stx_rectify_u8_dev(ctx, dsrc, w, h, p, img, drect, w, h, p, img, hinv, 2, STX_RECT_DST_IS_ZERO);
+    if (rc) return rc;
+    rc = stx_launch_disparity(ctx, drect, drect + img, 1, w, h, p, 0, 0, h, win, max_disp, cost_mode, dout, p,
+                              0, 1);
+    if (rc) return rc;
+    STX_HIP(hipMemcpy2DAsync(out, out_stride, dout, p, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, s));
+    if (rect0) STX_HIP(hipMemcpy2DAsync(rect0, rect_stride, drect, p, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, s));
+    if (rect1)
+        STX_HIP(hipMemcpy2DAsync(rect1, rect_stride, drect + img, p, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, s));
+    STX_HIP(hipStreamSynchronize(s));
+    return STX_OK;
 }

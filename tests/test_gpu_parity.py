@@ -351,6 +351,22 @@ def test_rectify_dev_batch_full_size(ctx, oracle):
         assert (d[k].cpu().numpy() == want).all()
 
 
+def test_rectify_then_disparity_fused(ctx, oracle):
+    """main.cpp:362-380 (rectify both, then scan) without leaving the GPU."""
+    h, w = 120, 333
+    a = synth.texture(11, h, w)
+    b = synth.texture(12, h, w)
+    H0, H1 = synth.homography(1, w, h, deg_y=1.0), synth.homography(2, w, h, deg_y=-1.5)
+    i0, i1 = oracle.invert3x3(H0), oracle.invert3x3(H1)
+    r0 = oracle.rectify(a, np.zeros((h, w), np.uint8), i0)
+    r1 = oracle.rectify(b, np.zeros((h, w), np.uint8), i1)
+    for win, D in [(1, 0), (9, 64)]:
+        want = oracle.disparity_ext(r0, r1, win, D, 0)
+        got, g0, g1 = ctx.rectify_disparity(a, b, i0, i1, win=win, max_disp=D, want_rectified=True)
+        assert (g0 == r0).all() and (g1 == r1).all() and (got == want).all()
+    assert (r0 == 0).any() and (r0 != 0).any()  # zero borders exercise the zero-skip
+
+
 # ------------------------------------------------------------------ M ------
 
 def _match_equal(got, want):
@@ -367,7 +383,7 @@ def _match_equal(got, want):
             assert g.tobytes() == w.tobytes(), "%s differs at %s" % (n, np.nonzero(g != w)[0][:8])
 
 
-ALGOS = [api.MATCH_EXACT, api.MATCH_MFMA, api.MATCH_AUTO]
+ALGOS = [api.MATCH_EXACT, api.MATCH_MFMA, api.MATCH_MFMA_BF16, api.MATCH_AUTO]
 
 
 @pytest.mark.parametrize("algo", ALGOS)
