@@ -234,7 +234,9 @@ __global__ __launch_bounds__(256) void match_norm_kernel(const float *__restrict
             s = fmaf(v.w, v.w, s);
         }
     }
-    norm2[r] = s;
+    // keep sums of two norms finite; anything larger (or inf/NaN) becomes NaN, which the
+    // prefilter treats as "cannot be bounded": the row / query is always a candidate
+    norm2[r] = s <= 1e37f ? s : __builtin_nanf("");
 }
 
 __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_kernel(
@@ -357,6 +359,90 @@ __device__ __forceinline__ void bf16_split8(const float4 &x, const float4 &y, ui
     lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
+
+// ---- pieces of the pipelined bf16 prefilter --------------------------------
+struct BoundState {
+    float naL, naU;  // |a|^2 (1 -+ c) -+ tiny for this lane's query
+    float m;         // running min of the upper bounds U seen so far
+    unsigned mask;   // bit (15 - r) set: row r of the current block may be a record
+};
+
+// mask = 2*mask + !(L > m)   (v_cmp_ngt: true for NaN), then m = min(m, U)
+__device__ __forceinline__ void bound_test(BoundState &b, float L, float U)
+{
+    asm("v_cmp_ngt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+        : "+v"(b.mask) : "v"(L), "v"(b.m) : "vcc");
+    asm("v_min_f32 %0, %0, %1" : "+v"(b.m) : "v"(U));
+}
+
+// rows of this lane in a 32-row block, in accumulator-register order r = 0..15:
+//   j = j0 + (r&3) + 8*(r>>2) + 4*half
+__device__ __forceinline__ void load_bnorm(const float *__restrict__ bnorm, int j0, int half, float (&nbv)[16])
+{
+    const float4 *nb4 = reinterpret_cast<const float4 *>(bnorm + j0 + 4 * half);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = nb4[2 * q];
+        nbv[4 * q] = v.x; nbv[4 * q + 1] = v.y; nbv[4 * q + 2] = v.z; nbv[4 * q + 3] = v.w;
+    }
+}
+
+// epilogue slice for k-step s: accumulator registers 2s and 2s+1 of both column blocks
+__device__ __forceinline__ void bound_step(const f32x16 &p0, const f32x16 &p1, int s, const float (&nbv)[16],
+                                           float cL, float cU, BoundState &b0, BoundState &b1)
+{
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int r = 2 * s + e;
+        const float sl0 = fmaf(nbv[r], cL, b0.naL), su0 = fmaf(nbv[r], cU, b0.naU);
+        const float sl1 = fmaf(nbv[r], cL, b1.naL), su1 = fmaf(nbv[r], cU, b1.naU);
+        bound_test(b0, fmaf(-2.0f, p0[r], sl0), fmaf(-2.0f, p0[r], su0));
+        bound_test(b1, fmaf(-2.0f, p1[r], sl1), fmaf(-2.0f, p1[r], su1));
+    }
+}
+
+// one 32-row block: 48 MFMAs into (n0, n1); if EPI, the epilogue of the previous block
+// (accumulators p0, p1) is sliced between the k-steps
+template <bool EPI>
+__device__ __forceinline__ void mfma_block(const uint4 *bf, const bf16x8 (&qh0)[8], const bf16x8 (&ql0)[8],
+                                           const bf16x8 (&qh1)[8], const bf16x8 (&ql1)[8], f32x16 &n0,
+                                           f32x16 &n1, const f32x16 &p0, const f32x16 &p1,
+                                           const float (&nbv)[16], float cL, float cU, BoundState &b0,
+                                           BoundState &b1)
+{
+    f32x16 a0 = {0}, a1 = {0};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bf[(2 * s) * 64]);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, bf[(2 * s + 1) * 64]);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, qh0[s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, qh1[s], a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ql0[s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ql1[s], a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, qh0[s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, qh1[s], a1, 0, 0, 0);
+        if (EPI) bound_step(p0, p1, s, nbv, cL, cU, b0, b1);
+    }
+    n0 = a0;
+    n1 = a1;
+}
+
+// append the flagged rows of one block to query qi's candidate list (few lanes, rare)
+__device__ __forceinline__ void emit_flagged(unsigned mask, int qi, int j0, int half, int n2,
+                                             int *__restrict__ cand_count, int *__restrict__ cand)
+{
+    while (mask) {
+        const int bit = 31 - __clz((int)mask);
+        mask &= ~(1u << bit);
+        const int r = 15 - bit;
+        const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (j < n2) {
+            const int pos = atomicAdd(cand_count + qi, 1);
+            if (pos < MF_CAP) cand[(size_t)qi * MF_CAP + pos] = j;
+        }
+    }
+}
+
 // list2 -> A-operand fragment order of v_mfma_f32_32x32x16_bf16 (lane holds
 // A[row = lane&31][k = 16s + 8*(lane>>5) + 0..7]):
 //   frag16[((jb*8 + s)*2 + part)*64 + lane]  (uint4 = 8 bf16), part 0 = hi, 1 = lo
@@ -415,9 +501,16 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16_kernel(
             ql1[s] = __builtin_bit_cast(bf16x8, l);
         }
     }
+    // Bound in product form: with s = |a|^2 + |b|^2, L = s(1-c) - tiny - 2 a.b and
+    // U = s(1+c) + tiny - 2 a.b, so the per-element work is two fma to form s(1-+c), two
+    // fma for L and U, one compare and one min.  Norms above 1e37 or non-finite were
+    // replaced by NaN (match_norm_kernel), which makes L NaN and therefore emits.
+    const float cL = 1.0f - MF_C_BF16, cU = 1.0f + MF_C_BF16;
     const float na0 = live0 ? qnorm[q0i] : 0.f;
     const float na1 = live1 ? qnorm[q1i] : 0.f;
-    float m0 = __builtin_inff(), m1 = __builtin_inff();
+    BoundState b0, b1;
+    b0.naL = na0 * cL - MF_TINY; b0.naU = na0 * cU + MF_TINY; b0.m = __builtin_inff(); b0.mask = 0;
+    b1.naL = na1 * cL - MF_TINY; b1.naU = na1 * cU + MF_TINY; b1.m = __builtin_inff(); b1.mask = 0;
 
     const int t_begin = blockIdx.y * tiles_per_seg;
     const int t_end = min(t_begin + tiles_per_seg, tiles_total);
@@ -433,34 +526,51 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16_kernel(
                 (__attribute__((address_space(3))) void *)(&tile[buf][chunk]), 16, 0, 0);
         }
     };
+    // close a row block whose epilogue has run: share the bound between the two half-waves
+    // (they saw disjoint rows of the same queries) and append the flagged rows
+    auto finish = [&](int j0) {
+        b0.m = fminf(b0.m, __shfl_xor(b0.m, 32));
+        b1.m = fminf(b1.m, __shfl_xor(b1.m, 32));
+        const unsigned k0 = live0 ? b0.mask : 0u, k1 = live1 ? b1.mask : 0u;
+        if (__any((k0 | k1) != 0u)) {
+            emit_flagged(k0, q0i, j0, half, n2, cand_count, cand);
+            emit_flagged(k1, q1i, j0, half, n2, cand_count, cand);
+        }
+        b0.mask = 0;
+        b1.mask = 0;
+    };
 
     stage(t_begin, 0);
     __syncthreads();
 
+    // Software pipeline over row blocks: while the 48 MFMAs of block k are issued into one
+    // accumulator pair, the epilogue of block k-1 runs on the other pair, four elements per
+    // k-step, so that the VALU work sits in the gaps between MFMA issues of the same wave.
+    f32x16 x0, x1, y0, y1;
+    float nbv[16];
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
         if (t + 1 < t_end) stage(t + 1, buf ^ 1);
-
-        for (int jb = 0; jb < MF_TJ; ++jb) {
-            const uint4 *bf = tile[buf] + jb * 1024 + lane;
-            f32x16 acc0 = {0}, acc1 = {0};
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, bf[(2 * s) * 64]);
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, bf[(2 * s + 1) * 64]);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, qh0[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, qh1[s], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ql0[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ql1[s], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, qh0[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, qh1[s], acc1, 0, 0, 0);
-            }
-            prefilter_epilogue(acc0, acc1, (t * MF_TJ + jb) * MF_JB, half, bnorm, n2, na0, na1, live0, live1,
-                               q0i, q1i, MF_C_BF16, m0, m1, cand_count, cand);
-            m0 = fminf(m0, __shfl_xor(m0, 32));
-            m1 = fminf(m1, __shfl_xor(m1, 32));
+        const uint4 *bf = tile[buf] + lane;
+        const int j0 = t * MF_TILE_ROWS;
+        if (t == t_begin) {
+            mfma_block<false>(bf, qh0, ql0, qh1, ql1, x0, x1, y0, y1, nbv, cL, cU, b0, b1);
+        } else {
+            load_bnorm(bnorm, j0 - MF_JB, half, nbv);
+            mfma_block<true>(bf, qh0, ql0, qh1, ql1, x0, x1, y0, y1, nbv, cL, cU, b0, b1);
+            finish(j0 - MF_JB);
         }
+        load_bnorm(bnorm, j0, half, nbv);
+        mfma_block<true>(bf + 1024, qh0, ql0, qh1, ql1, y0, y1, x0, x1, nbv, cL, cU, b0, b1);
+        finish(j0);
         __syncthreads();
+    }
+    {   // drain: epilogue of the last block
+        const int j0 = (t_end - 1) * MF_TILE_ROWS + MF_JB;
+        load_bnorm(bnorm, j0, half, nbv);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) bound_step(y0, y1, s, nbv, cL, cU, b0, b1);
+        finish(j0);
     }
 }
 
