@@ -219,7 +219,7 @@ __global__ __launch_bounds__(EXT_THREADS) void disp_ext_bruteforce_kernel(
 // The horizontal window sum slides across the lane's 4 columns and takes the
 // columns it lacks from the neighbouring lanes with wave_shr:1 / wave_shl:1 DPP
 // adds (window radius <= 4 => one lane to each side).  The key
-//     (cost << BAND_SH) | (4095 - d) | mask(img1[y][x-d] == 0 or x-d < 0)
+//     (cost << BAND_SH) + (4095 - d) + mask(img1[y][x-d] == 0 or x-d < 0)
 // is reduced with v_min3_u32 over the wave's 16 disparities, then across the
 // workgroup's waves with one LDS atomic min per pixel: smallest cost wins, equal
 // costs go to the larger d = the lower x1, which is the reference's strict-'<'
@@ -231,8 +231,13 @@ constexpr int BAND_ND = 16;          // disparities per wave
 constexpr int BAND_COLS = 256;       // columns per tile (64 lanes x 4)
 constexpr unsigned BAND_SH = 12;     // key = cost << 12 | (4095 - d)
 constexpr unsigned BAND_LOW = (1u << BAND_SH) - 1;
-constexpr unsigned BAND_INIT = 0xFFFFFFFEu;  // "no candidate yet": above every valid key
-constexpr unsigned BAND_MASKED = 0xFFFFFFFFu;
+// Valid keys stay below 2^28 (cost <= 255*81 < 2^15, shifted by 12).  An invalid candidate
+// (img1 centre 0 or left of the image) adds BAND_MASKED, a disparity past D adds
+// BAND_PAST_D; the two can add up without wrapping, and "no candidate yet" (BAND_INIT)
+// lies above every valid key and below every invalidated one.
+constexpr unsigned BAND_MASKED = 0x80000000u;
+constexpr unsigned BAND_PAST_D = 0x40000000u;
+constexpr unsigned BAND_INIT = 0x3FFFFFFFu;
 constexpr int BAND_MAX_WAVES = 16;
 
 // |a - b| + c in one instruction.  Written as asm because hipcc only matches the
@@ -365,12 +370,25 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
         }
     };
 
+    // Column sums.  The disparity code of the key, (4095 - d), is folded into the sums: it is
+    // the initial value of V in exactly the columns x with x mod WIN == 0 -- every WIN-wide
+    // window holds exactly one such column, the sliding add/subtract of rows never touches
+    // the constant, so each window cost comes out as (cost << 12) + (4095 - d) with no extra
+    // instruction.  Disparities past D (partial last block) carry BAND_PAST_D the same way.
     unsigned V[BAND_ND][4];
+    {
+        bool carrier[4];
 #pragma unroll
-    for (int dd = 0; dd < BAND_ND; ++dd)
+        for (int c = 0; c < 4; ++c) carrier[c] = ((x0 + 4 * lane + c + 1024 * WIN) % WIN) == 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) V[dd][c] = 0;
+        for (int dd = 0; dd < BAND_ND; ++dd) {
+            const unsigned code = dB + dd < a.D ? BAND_LOW - (unsigned)(dB + dd) : BAND_PAST_D;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) V[dd][c] = carrier[c] ? code : 0u;
+        }
+    }
 
+    unsigned W1[R == 0 ? BAND_ND : 1][4];  // R == 0 only: this row's costs
     const int ys0 = yb - R, ys1 = yend - 1 + R;  // streamed rows
     fill_load(ys0);
     fill_store(ys0);
@@ -395,8 +413,8 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
             for (int dd = 0; dd < BAND_ND; ++dd)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if (R == 0)
-                        V[dd][c] = sad_u32_0(rv[16 + c - dd], lv[c]);
+                    if (R == 0)  // 1x1 window: the sum is one term; V only holds the code
+                        W1[dd][c] = sad_u32(rv[16 + c - dd], lv[c], V[dd][c]);
                     else
                         V[dd][c] = sad_u32(rv[16 + c - dd], lv[c], V[dd][c]);
                 }
@@ -430,16 +448,14 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
                 const u32x4 t = lds_read_b128(mp + j);
                 mv[4 * j] = t.x; mv[4 * j + 1] = t.y; mv[4 * j + 2] = t.z; mv[4 * j + 3] = t.w;
             }
-            unsigned m[4] = {BAND_MASKED, BAND_MASKED, BAND_MASKED, BAND_MASKED};
+            unsigned m[4] = {~0u, ~0u, ~0u, ~0u};
             unsigned pend[4];
 #pragma unroll
             for (int dd = 0; dd < BAND_ND; ++dd) {
-                // disparities past D (partial last block) get an all-ones key (wave-uniform)
-                const unsigned low = dB + dd < a.D ? BAND_LOW - (unsigned)(dB + dd) : BAND_MASKED;
                 unsigned cost[4];
                 if (R == 0) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) cost[c] = V[dd][c];
+                    for (int c = 0; c < 4; ++c) cost[c] = W1[dd][c];
                 } else {
                     // cost[c] = sum of V over columns c-R .. c+R; columns < 0 live in the
                     // left neighbour lane (as its column +4), columns > 3 in the right one
@@ -471,7 +487,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const unsigned key = cost[c] | mv[16 + c - dd] | low;
+                    const unsigned key = cost[c] + mv[16 + c - dd];  // mask word: 0 or BAND_MASKED
                     if (dd & 1)
                         m[c] = min3_u32(m[c], pend[c], key);
                     else
