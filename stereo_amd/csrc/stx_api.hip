@@ -210,6 +210,24 @@ extern "C" int stx_invert_homography(const float H[9], float Hinv[9])
     return STX_OK;
 }
 
+
+// Host <-> device image copies.  hipMemcpy2DAsync on pageable memory runs at well under
+// 1 GB/s on this stack (measured: 51 ms for three 5.7 MB images), a flat hipMemcpyAsync at
+// ~16 GB/s, so densely packed host images (stride == width, the cv::Mat::zeros / imread
+// case) are copied flat into an equally dense device image; only pitched views take the 2-D path.
+static hipError_t copy_image_h2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t wbytes,
+                                 size_t h, hipStream_t s)
+{
+    if (dpitch == wbytes && spitch == wbytes) return hipMemcpyAsync(dst, src, wbytes * h, hipMemcpyHostToDevice, s);
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, wbytes, h, hipMemcpyHostToDevice, s);
+}
+static hipError_t copy_image_d2h(void *dst, size_t dpitch, const void *src, size_t spitch, size_t wbytes,
+                                 size_t h, hipStream_t s)
+{
+    if (dpitch == wbytes && spitch == wbytes) return hipMemcpyAsync(dst, src, wbytes * h, hipMemcpyDeviceToHost, s);
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, wbytes, h, hipMemcpyDeviceToHost, s);
+}
+
 static int check_image(const void *p, int w, int h, size_t stride)
 {
     if (w < 0 || h < 0) return STX_ERR_INVALID_ARG;
@@ -255,22 +273,19 @@ extern "C" int stx_rectify_u8(stx_ctx *ctx, const uint8_t *src, int src_w, int s
     if (dst_w == 0 || dst_h == 0) return STX_OK;
     int err;
     hipStream_t s = ctx->stream;
-    // device copies are densely pitched to a multiple of 16 bytes
-    const size_t sp = ((size_t)src_w + 15) & ~(size_t)15, dp = ((size_t)dst_w + 15) & ~(size_t)15;
+    // dense device images (pitch == width): see copy_image_h2d
+    const size_t sp = (size_t)(src_w > 0 ? src_w : 1), dp = (size_t)dst_w;
     uint8_t *dsrc = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG0, sp * (size_t)(src_h > 0 ? src_h : 1), &err);
     if (!dsrc) return err;
     uint8_t *ddst = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG1, dp * (size_t)dst_h, &err);
     if (!ddst) return err;
     if (src_w > 0 && src_h > 0)
-        STX_HIP(hipMemcpy2DAsync(dsrc, sp, src, src_stride, (size_t)src_w, (size_t)src_h,
-                                 hipMemcpyHostToDevice, s));
+        STX_HIP(copy_image_h2d(dsrc, sp, src, src_stride, (size_t)src_w, (size_t)src_h, s));
     if (flags == STX_RECT_PRESERVE_DST)
-        STX_HIP(hipMemcpy2DAsync(ddst, dp, dst, dst_stride, (size_t)dst_w, (size_t)dst_h,
-                                 hipMemcpyHostToDevice, s));
+        STX_HIP(copy_image_h2d(ddst, dp, dst, dst_stride, (size_t)dst_w, (size_t)dst_h, s));
     rc = stx_rectify_u8_dev(ctx, dsrc, src_w, src_h, sp, 0, ddst, dst_w, dst_h, dp, 0, Hinv, 1, flags);
     if (rc) return rc;
-    STX_HIP(hipMemcpy2DAsync(dst, dst_stride, ddst, dp, (size_t)dst_w, (size_t)dst_h,
-                             hipMemcpyDeviceToHost, s));
+    STX_HIP(copy_image_d2h(dst, dst_stride, ddst, dp, (size_t)dst_w, (size_t)dst_h, s));
     STX_HIP(hipStreamSynchronize(s));
     return STX_OK;
 }
@@ -347,7 +362,7 @@ static int disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1
     STX_HIP(hipSetDevice(ctx->device));
     int err;
     hipStream_t s = ctx->stream;
-    const size_t p = ((size_t)w + 15) & ~(size_t)15;
+    const size_t p = (size_t)w;  // dense device images: see copy_image_h2d
     const size_t op = p * (size_t)out_bytes;
     uint8_t *d0 = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG0, p * (size_t)h, &err);
     if (!d0) return err;
@@ -355,13 +370,12 @@ static int disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1
     if (!d1) return err;
     uint8_t *dout = (uint8_t *)stx_workspace(ctx, STX_SLOT_OUT, op * (size_t)h, &err);
     if (!dout) return err;
-    STX_HIP(hipMemcpy2DAsync(d0, p, img0, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, s));
-    STX_HIP(hipMemcpy2DAsync(d1, p, img1, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, s));
+    STX_HIP(copy_image_h2d(d0, p, img0, stride, (size_t)w, (size_t)h, s));
+    STX_HIP(copy_image_h2d(d1, p, img1, stride, (size_t)w, (size_t)h, s));
     rc = stx_launch_disparity(ctx, d0, d1, 1, w, h, p, 0, 0, h, win, max_disp, cost_mode, dout, op, 0,
                               out_bytes);
     if (rc) return rc;
-    STX_HIP(hipMemcpy2DAsync(out, out_stride, dout, op, (size_t)w * (size_t)out_bytes, (size_t)h,
-                             hipMemcpyDeviceToHost, s));
+    STX_HIP(copy_image_d2h(out, out_stride, dout, op, (size_t)w * (size_t)out_bytes, (size_t)h, s));
     STX_HIP(hipStreamSynchronize(s));
     return STX_OK;
 }
@@ -397,7 +411,7 @@ extern "C" int stx_rectify_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const
     STX_HIP(hipSetDevice(ctx->device));
     int err;
     hipStream_t s = ctx->stream;
-    const size_t p = ((size_t)w + 15) & ~(size_t)15;
+    const size_t p = (size_t)w;
     const size_t img = p * (size_t)h;
     // [src0 | src1] in IMG0, [rect0 | rect1] in IMG1, disparity in OUT
     uint8_t *dsrc = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG0, 2 * img, &err);
@@ -406,8 +420,8 @@ extern "C" int stx_rectify_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const
     if (!drect) return err;
     uint8_t *dout = (uint8_t *)stx_workspace(ctx, STX_SLOT_OUT, img, &err);
     if (!dout) return err;
-    STX_HIP(hipMemcpy2DAsync(dsrc, p, img0, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, s));
-    STX_HIP(hipMemcpy2DAsync(dsrc + img, p, img1, stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, s));
+    STX_HIP(copy_image_h2d(dsrc, p, img0, stride, (size_t)w, (size_t)h, s));
+    STX_HIP(copy_image_h2d(dsrc + img, p, img1, stride, (size_t)w, (size_t)h, s));
     float hinv[18];
     memcpy(hinv, Hinv0, 9 * sizeof(float));
     memcpy(hinv + 9, Hinv1, 9 * sizeof(float));
@@ -417,10 +431,9 @@ extern "C" int stx_rectify_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const
     rc = stx_launch_disparity(ctx, drect, drect + img, 1, w, h, p, 0, 0, h, win, max_disp, cost_mode, dout, p,
                               0, 1);
     if (rc) return rc;
-    STX_HIP(hipMemcpy2DAsync(out, out_stride, dout, p, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, s));
-    if (rect0) STX_HIP(hipMemcpy2DAsync(rect0, rect_stride, drect, p, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, s));
-    if (rect1)
-        STX_HIP(hipMemcpy2DAsync(rect1, rect_stride, drect + img, p, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, s));
+    STX_HIP(copy_image_d2h(out, out_stride, dout, p, (size_t)w, (size_t)h, s));
+    if (rect0) STX_HIP(copy_image_d2h(rect0, rect_stride, drect, p, (size_t)w, (size_t)h, s));
+    if (rect1) STX_HIP(copy_image_d2h(rect1, rect_stride, drect + img, p, (size_t)w, (size_t)h, s));
     STX_HIP(hipStreamSynchronize(s));
     return STX_OK;
 }
