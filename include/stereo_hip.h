@@ -184,6 +184,19 @@ int stx_disparity_rowband_dev(stx_ctx *ctx, const uint8_t *d_img0,
                               int max_disp, int cost_mode, void *d_out,
                               size_t out_stride, int out_bytes);
 
+/* ---- FAST-12 corner detection (upstream producer of M's inputs) -----------
+ * Replaces FindFASTFeatures (stereo/Features.cpp:407-471; decl Features.h:167-169):
+ * every pixel at least 3 from the border whose 16-point ring has 12 contiguous points all
+ * brighter than p + threshold or all darker than p - threshold (FAST_THRESHOLD = 30,
+ * Features.h:13).  xy receives up to max_out (x, y) float pairs in the reference's raster
+ * order (Feature::p); *count the total number found (may exceed max_out).  Host pointers. */
+int stx_fast_detect_u8(stx_ctx *ctx, const uint8_t *img, int w, int h, size_t stride, int threshold,
+                       float *xy, int max_out, int *count);
+
+/* Device-resident form (d_count is a device int); asynchronous. */
+int stx_fast_detect_u8_dev(stx_ctx *ctx, const uint8_t *d_img, int w, int h, size_t stride,
+                           int threshold, float *d_xy, int max_out, int *d_count);
+
 /* ---- R+D fused on the device ---------------------------------------------
  * main.cpp:362-380 in one call: both images are rectified into zero-initialised
  * destinations of the source size (RectifyImage twice, Stereography.cpp:596-631) and the

@@ -29,6 +29,7 @@ def lib():
         _lib = C.CDLL(_SO)
         _lib.oracle_descriptor_distance.restype = C.c_float
         _lib.oracle_bilinear.restype = C.c_uint8
+        _lib.oracle_fast_selfcheck.restype = C.c_long
     return _lib
 
 
@@ -102,3 +103,28 @@ def disparity_ext(img0, img1, win, max_disp, cost_mode=0, out_dtype=np.uint8, sl
     if rc != 0:
         raise ValueError("oracle_disparity_ext: invalid arguments")
     return out
+
+
+def check_sequential12(points, p_b, pb):
+    return bool(lib().oracle_check_sequential12((C.c_int * 16)(*[int(v) for v in points]), int(p_b), int(pb)))
+
+
+def ring_run12(points, p_b, pb):
+    return bool(lib().oracle_ring_run12((C.c_int * 16)(*[int(v) for v in points]), int(p_b), int(pb)))
+
+
+def three_of_four(i1, i5, i9, i13, pb, p_b):
+    return bool(lib().oracle_three_of_four(int(i1), int(i5), int(i9), int(i13), int(pb), int(p_b)))
+
+
+def fast_selfcheck():
+    return int(lib().oracle_fast_selfcheck())
+
+
+def fast_features(img, threshold=30):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = max(1, w * h)
+    xy = np.zeros((cap, 2), np.float32)
+    n = lib().oracle_fast_features(_p(img), w, h, C.c_size_t(max(w, 1)), int(threshold), _p(xy), cap)
+    return xy[:n].copy()

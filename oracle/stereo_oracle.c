@@ -365,3 +365,128 @@ int oracle_disparity_ext_sliding(const uint8_t *img0, const uint8_t *img1, int w
     free(best); free(bestx); free(col); free(pre);
     return 0;
 }
+
+/* ---------------------------------------------------------------- FAST --- */
+
+/* Features.cpp:534-602.  For each point that is brighter than pb (or darker than p_b) the
+ * reference walks forward around the ring while the same comparison holds, steps back one,
+ * then walks backward until it fails or meets the forward end, and accepts a total length
+ * of at least 12. */
+int oracle_check_sequential12(const int points[16], int p_b, int pb)
+{
+    for (int i = 0; i < 16; ++i) {
+        int bright;
+        if (points[i] > pb)
+            bright = 1;
+        else if (points[i] < p_b)
+            bright = 0;
+        else
+            continue;
+#define SAME(v) (bright ? (v) > pb : (v) < p_b)
+        int fLen = 0, fJ;
+        for (fJ = i + 1; fJ != i; ++fJ) { /* :566-577 */
+            if (fJ == 16) fJ = 0;
+            if (fJ == i) break;
+            if (SAME(points[fJ]))
+                fLen++;
+            else
+                break;
+        }
+        fJ--; /* :578 */
+        int bLen = 0;
+        for (int bJ = i - 1; bJ != i && bJ != fJ; --bJ) { /* :581-592 */
+            if (bJ == -1) bJ = 15;
+            if (bJ == i || bJ == fJ) break;
+            if (SAME(points[bJ]))
+                bLen++;
+            else
+                break;
+        }
+#undef SAME
+        if (fLen + bLen + 1 >= 12) return 1; /* :593-598 */
+    }
+    return 0;
+}
+
+static unsigned rot16(unsigned m, int k) { return ((m << k) | (m >> (16 - k))) & 0xFFFFu; }
+
+static int mask_has_run12(unsigned m)
+{
+    unsigned x2 = m & rot16(m, 1);
+    unsigned x4 = x2 & rot16(x2, 2);
+    unsigned x8 = x4 & rot16(x4, 4);
+    return (x8 & rot16(x8, 4)) != 0;
+}
+
+int oracle_ring_run12(const int points[16], int p_b, int pb)
+{
+    unsigned bright = 0, dark = 0;
+    for (int i = 0; i < 16; ++i) {
+        if (points[i] > pb) bright |= 1u << i;
+        if (points[i] < p_b) dark |= 1u << i;
+    }
+    return mask_has_run12(bright) || mask_has_run12(dark);
+}
+
+/* Features.cpp:477-517 */
+int oracle_three_of_four(int i1, int i5, int i9, int i13, int pb, int p_b)
+{
+    if ((p_b < i1 && i1 < pb) && (p_b < i9 && i9 < pb)) return 0;   /* :481-484 */
+    if ((p_b < i5 && i5 < pb) && (p_b < i13 && i13 < pb)) return 0; /* :485-488 */
+    int above = (i1 > pb) + (i5 > pb) + (i9 > pb) + (i13 > pb);     /* :494-497 */
+    if (above >= 3) return 1;
+    int below = (i1 < p_b) + (i5 < p_b) + (i9 < p_b) + (i13 < p_b); /* :504-507 */
+    return below >= 3;
+}
+
+/* Features.cpp:407-471.  Ring order exactly as the reference lists it at :429-453
+ * (its points 8 and 10 are (h+3, w-1) and (h+3, w+1), i.e. swapped with respect to a
+ * clockwise walk; kept). */
+int oracle_fast_features(const uint8_t *img, int w, int h, size_t stride, int threshold,
+                         float *xy_out, int max_out)
+{
+    static const int dy[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
+    static const int dx[16] = {0, 1, 2, 3, 3, 3, 2, -1, 0, 1, -2, -3, -3, -3, -2, -1};
+    int count = 0;
+    for (int y = 3; y < h - 3; ++y) {
+        for (int x = 3; x < w - 3; ++x) {
+            int p = img[(size_t)y * stride + x];
+            int pb = p + threshold, p_b = p - threshold; /* :421-423 */
+            int pts[16];
+            for (int k = 0; k < 16; ++k) pts[k] = img[(size_t)(y + dy[k]) * stride + (x + dx[k])];
+            if (!oracle_three_of_four(pts[0], pts[4], pts[8], pts[12], pb, p_b)) continue; /* :433 */
+            if (!oracle_check_sequential12(pts, p_b, pb)) continue;                         /* :456 */
+            if (count < max_out && xy_out) {
+                xy_out[2 * count] = (float)x;     /* feature.p.x = w, :463 */
+                xy_out[2 * count + 1] = (float)y; /* feature.p.y = h, :464 */
+            }
+            ++count;
+        }
+    }
+    return count;
+}
+
+/* Exhaustive agreement of the literal scan with the run-length statement over all 3^16
+ * bright / dark / neither ring patterns, and of the three-of-four pretest being a pure
+ * filter (it never rejects a ring that has a run of 12).  Returns the number of
+ * disagreements (0 expected).  Used by tests only. */
+long oracle_fast_selfcheck(void)
+{
+    long bad = 0;
+    int pts[16];
+    const int p_b = 30, pb = 90; /* 0 = dark, 60 = neither, 91 = bright */
+    static const int val[3] = {0, 60, 91};
+    long total = 43046721; /* 3^16 */
+    for (long code = 0; code < total; ++code) {
+        long c = code;
+        for (int i = 0; i < 16; ++i) {
+            pts[i] = val[c % 3];
+            c /= 3;
+        }
+        int a = oracle_check_sequential12(pts, p_b, pb);
+        int b = oracle_ring_run12(pts, p_b, pb);
+        if (a != b) ++bad;
+        if (b && !oracle_three_of_four(pts[0], pts[4], pts[8], pts[12], pb, p_b)) ++bad;
+    }
+    return bad;
+}

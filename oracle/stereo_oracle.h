@@ -92,6 +92,26 @@ int oracle_disparity_ext_sliding(const uint8_t *img0, const uint8_t *img1, int w
                                  int cost_mode, void *out, size_t out_stride_bytes,
                                  int out_bytes);
 
+/* ---- FAST-12 detection -------------------------------------
+ * CheckForSequential12, stereo/Features.cpp:534-602: points[16] in the reference's ring
+ * order, p_b/pb the lower/upper thresholds.  Pinned by the reference's own
+ * TestSequential12 vectors (Features.cpp:605-641), see tests/test_oracle_kat.py. */
+int oracle_check_sequential12(const int points[16], int p_b, int pb);
+
+/* The same predicate stated as "a circular run of >= 12 points all > pb or all < p_b"
+ * (what the GPU kernel evaluates with bit masks); tests prove the two agree on all 3^16
+ * bright/dark/neither patterns. */
+int oracle_ring_run12(const int points[16], int p_b, int pb);
+
+/* ThreeOfFourValuesBrighterOrDarker, stereo/Features.cpp:477-517 */
+int oracle_three_of_four(int i1, int i5, int i9, int i13, int pb, int p_b);
+
+/* FindFASTFeatures, stereo/Features.cpp:407-471, with FAST_THRESHOLD (Features.h:13) as
+ * a parameter.  Writes up to max_out (x, y) pairs in the reference's raster order
+ * (feature.p.x = w, feature.p.y = h); returns the total number of corners found. */
+int oracle_fast_features(const uint8_t *img, int w, int h, size_t stride, int threshold,
+                         float *xy_out, int max_out);
+
 #ifdef __cplusplus
 }
 #endif

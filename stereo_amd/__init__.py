@@ -15,6 +15,7 @@ from .api import (
     Context,
     Feature,
     MatchDescriptors,
+    FindFASTFeatures,
     RectifyImage,
     ComputeDepthImage,
     MATCH_FAILED,
@@ -27,7 +28,7 @@ from .api import (
 
 __all__ = [
     "StereoHipError", "load_library", "library_path", "Context", "Feature",
-    "MatchDescriptors", "RectifyImage", "ComputeDepthImage",
+    "MatchDescriptors", "FindFASTFeatures", "RectifyImage", "ComputeDepthImage",
     "MATCH_FAILED", "MATCH_SCORE", "MATCH_RATIO", "MATCH_ACCEPTED",
     "NN_RATIO", "MAX_DIST_BETWEEN_MATCHES",
 ]

@@ -60,6 +60,9 @@ PROTOTYPES = {
     "stx_disparity_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t,
                                     C.c_size_t, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t,
                                     C.c_size_t, C.c_int]),
+    "stx_fast_detect_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, C.c_int, _vp, C.c_int,
+                                     C.POINTER(C.c_int)]),
+    "stx_fast_detect_u8_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, C.c_int, _vp, C.c_int, _vp]),
     "stx_rectify_disparity_u8": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_size_t, _f32p, _f32p,
                                            C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp, _vp,
                                            C.c_size_t]),

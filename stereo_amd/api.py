@@ -25,6 +25,7 @@ from ._lib import check
 NN_RATIO = 0.8
 MAX_DIST_BETWEEN_MATCHES = 1000.0
 DESC_LENGTH = 128
+FAST_THRESHOLD = 30  # stereo/Features.h:13
 
 MATCH_FAILED, MATCH_SCORE, MATCH_RATIO, MATCH_ACCEPTED = 0, 1, 2, 3
 COST_SAD, COST_SSD = 0, 1
@@ -151,6 +152,26 @@ class Context:
             int(d3.stride(1)), int(d3.stride(0)), Hinv.ctypes.data_as(C.POINTER(C.c_float)), n,
             int(flags)), "stx_rectify_u8_dev")
 
+    # -- FAST -----------------------------------------------------------------
+    def fast_detect(self, img, threshold=FAST_THRESHOLD, max_out=None):
+        """(xy float32 [n,2] in raster order, total count)."""
+        _check_image(img, "img")
+        h, w = img.shape
+        if max_out is None:
+            max_out = max(1, w * h // 4)
+        xy = np.zeros((max_out, 2), np.float32)
+        cnt = C.c_int(0)
+        check(self._lib.stx_fast_detect_u8(self._h, _ptr(img), w, h,
+                                           img.strides[0] if h > 1 else max(w, 1), int(threshold),
+                                           _ptr(xy), int(max_out), C.byref(cnt)), "stx_fast_detect_u8")
+        return xy[:min(cnt.value, max_out)], cnt.value
+
+    def fast_detect_dev(self, img, xy, count, threshold=FAST_THRESHOLD):
+        """img: [H,W] uint8 device tensor; xy: [max,2] float32; count: int32[1] device tensor."""
+        check(self._lib.stx_fast_detect_u8_dev(self._h, img.data_ptr(), int(img.shape[1]), int(img.shape[0]),
+                                               int(img.stride(0)), int(threshold), xy.data_ptr(),
+                                               int(xy.shape[0]), count.data_ptr()), "stx_fast_detect_u8_dev")
+
     # -- D ------------------------------------------------------------------
     def disparity(self, img0, img1, win=1, max_disp=0, cost_mode=COST_SAD, out_dtype=np.uint8):
         _check_image(img0, "img0")
@@ -274,6 +295,16 @@ def MatchDescriptors(list1, list2, distLimitBetweenMatches, ctx=None, out=None):
         b.distFromBestMatch = float(min_dist[i])
         matches.append((a, b))
     return matches
+
+
+def FindFASTFeatures(img, features, ctx=None):
+    """FindFASTFeatures, stereo/Features.cpp:407-471: appends one Feature per FAST-12 corner
+    (p = (x, y), raster order) to `features`; returns True like the reference."""
+    ctx = ctx or default_context()
+    xy, _ = ctx.fast_detect(img, FAST_THRESHOLD)
+    for x, y in xy:
+        features.append(Feature(p=(float(x), float(y))))
+    return True
 
 
 def RectifyImage(original, rectified, H, ctx=None):

@@ -437,3 +437,47 @@ extern "C" int stx_rectify_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const
     STX_HIP(hipStreamSynchronize(s));
     return STX_OK;
 }
+
+// ------------------------------------------------------------------- FAST --
+
+extern "C" int stx_fast_detect_u8_dev(stx_ctx *ctx, const uint8_t *d_img, int w, int h, size_t stride,
+                                      int threshold, float *d_xy, int max_out, int *d_count)
+{
+    if (!ctx || !d_count || max_out < 0 || (max_out > 0 && !d_xy)) return STX_ERR_INVALID_ARG;
+    int rc = check_image(d_img, w, h, stride);
+    if (rc) return rc;
+    STX_HIP(hipSetDevice(ctx->device));
+    if (w == 0 || h == 0) return (int)hipMemsetAsync(d_count, 0, sizeof(int), ctx->stream);
+    return stx_launch_fast(ctx, d_img, w, h, stride, threshold, d_xy, max_out, d_count);
+}
+
+extern "C" int stx_fast_detect_u8(stx_ctx *ctx, const uint8_t *img, int w, int h, size_t stride,
+                                  int threshold, float *xy, int max_out, int *count)
+{
+    if (!ctx || !count || max_out < 0 || (max_out > 0 && !xy)) return STX_ERR_INVALID_ARG;
+    int rc = check_image(img, w, h, stride);
+    if (rc) return rc;
+    *count = 0;
+    if (w == 0 || h == 0) return STX_OK;
+    STX_HIP(hipSetDevice(ctx->device));
+    int err;
+    hipStream_t s = ctx->stream;
+    const size_t p = (size_t)w;
+    uint8_t *dimg = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG0, p * (size_t)h, &err);
+    if (!dimg) return err;
+    float *dxy = (float *)stx_workspace(ctx, STX_SLOT_OUT, sizeof(float) * 2 * (size_t)max_out + 16, &err);
+    if (!dxy) return err;
+    int *dcount = (int *)stx_workspace(ctx, STX_SLOT_SMALL, 64, &err);
+    if (!dcount) return err;
+    STX_HIP(copy_image_h2d(dimg, p, img, stride, (size_t)w, (size_t)h, s));
+    rc = stx_launch_fast(ctx, dimg, w, h, p, threshold, dxy, max_out, dcount);
+    if (rc) return rc;
+    STX_HIP(hipMemcpyAsync(count, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
+    STX_HIP(hipStreamSynchronize(s));
+    const int n = *count < max_out ? *count : max_out;
+    if (n > 0) {
+        STX_HIP(hipMemcpyAsync(xy, dxy, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, s));
+        STX_HIP(hipStreamSynchronize(s));
+    }
+    return STX_OK;
+}

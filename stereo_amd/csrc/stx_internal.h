@@ -21,6 +21,7 @@ enum stx_slot {
     STX_SLOT_M_QNORM,    // match: query norms
     STX_SLOT_M_CAND,     // match: candidate lists + counters
     STX_SLOT_M_FALLBACK, // match: overflow query list
+    STX_SLOT_FAST,       // FAST: corner bit words + prefix sums
     STX_SLOT_COUNT
 };
 
@@ -60,3 +61,6 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
                      const float *d_desc2, const float *d_score2, int n2,
                      float dist_limit, int32_t *d_closest, int32_t *d_second,
                      float *d_min_dist, float *d_second_dist, uint8_t *d_status);
+
+int stx_launch_fast(stx_ctx *ctx, const uint8_t *d_img, int w, int h, size_t stride, int threshold,
+                    float *d_xy, int max_out, int *d_count);

@@ -484,3 +484,54 @@ def test_match_descriptors_reference_signature(ctx, oracle):
     assert [int(p[0].p[0]) for p in pairs] == acc
     assert [int(p[1].p[0]) for p in pairs] == [int(c[i]) for i in acc]
     assert "Error: failed to match feature 7\n" in log.getvalue()
+
+
+# --------------------------------------------------------------- FAST ------
+
+def _corner_image(seed, h, w):
+    """Texture with sharp rectangles so that FAST finds a few thousand corners."""
+    img = synth.texture(seed, h, w).astype(np.int32) // 2 + 40
+    rng = np.random.RandomState(seed)
+    for _ in range(max(4, h * w // 1500)):
+        y, x = rng.randint(0, h - 4), rng.randint(0, w - 4)
+        hh, ww = rng.randint(3, 20), rng.randint(3, 20)
+        img[y:y + hh, x:x + ww] = rng.choice([0, 255, 20, 230])
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("h,w", [(7, 7), (8, 70), (64, 64), (50, 129), (120, 333), (500, 741)])
+def test_fast_matches_oracle(ctx, oracle, h, w):
+    img = _corner_image(h + w, h, w)
+    want = oracle.fast_features(img, 30)
+    got, n = ctx.fast_detect(img, 30)
+    assert n == len(want)
+    assert got.tobytes() == want.tobytes()  # same corners in the same raster order
+
+
+def test_fast_edge_cases(ctx, oracle):
+    assert ctx.fast_detect(np.zeros((6, 100), np.uint8))[1] == 0       # too small for the 3-pixel border
+    assert ctx.fast_detect(np.zeros((100, 6), np.uint8))[1] == 0
+    assert ctx.fast_detect(np.zeros((0, 0), np.uint8))[1] == 0
+    img = _corner_image(5, 90, 200)
+    want = oracle.fast_features(img, 30)
+    got, n = ctx.fast_detect(img, 30, max_out=10)                       # truncated output keeps the order
+    assert n == len(want) and (got == want[:10]).all()
+    for t in (1, 10, 100, 254):                                         # other thresholds
+        assert ctx.fast_detect(img, t)[0].tobytes() == oracle.fast_features(img, t).tobytes()
+    big = np.zeros((90, 300), np.uint8); big[:, 50:250] = img            # pitched view
+    assert ctx.fast_detect(big[:, 50:250], 30)[0].tobytes() == want.tobytes()
+
+
+def test_find_fast_features_reference_signature(ctx, oracle):
+    img = _corner_image(9, 120, 160)
+    feats = [api.Feature(p=(-1.0, -1.0))]
+    assert api.FindFASTFeatures(img, feats, ctx=ctx) is True
+    want = oracle.fast_features(img, api.FAST_THRESHOLD)
+    assert [f.p for f in feats[1:]] == [(float(x), float(y)) for x, y in want] and len(want) > 10
+
+
+def test_fast_full_size(ctx, oracle):
+    img = _corner_image(77, 1988, 2880)
+    got, n = ctx.fast_detect(img, 30)
+    want = oracle.fast_features(img, 30)
+    assert n == len(want) > 1000 and got.tobytes() == want.tobytes()

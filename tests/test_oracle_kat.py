@@ -219,3 +219,60 @@ def test_match_duplicate_descriptors_nan_ratio(oracle):
     assert (c[0], se[0], md[0], st[0]) == (1, 0, 0.0, 3)  # 0/1 = 0 < .8 accepted
     c, se, md, sd, st = oracle.match(q, np.zeros(1, np.float32), _axis_desc([2, 2]), np.zeros(2, np.float32))
     assert (c[0], se[0], st[0]) == (0, -1, 0)  # tie -> first wins -> closest 0 -> failed
+
+
+# --------------------------------------------------------------- FAST ------
+
+
+def test_sequential12_reference_vectors(oracle):
+    """The reference's OWN known-answer vectors: TestSequential12, stereo/Features.cpp:605-641
+    (the only golden vectors the reference holds anywhere near this path)."""
+    z = [0] * 16
+    assert not oracle.check_sequential12(z, 0, 1)                                   # :608-612
+    assert oracle.check_sequential12(z, 1, 3)                                       # :614-618
+    cases = [  # p_b = 30, pb = 90, :620-639
+        ([0, 91, 0, 91, 91, 91, 91, 91, 91, 91, 91, 91, 91, 91, 91, 0], True),
+        ([0, 91, 0, 0, 91, 91, 91, 91, 91, 91, 91, 91, 91, 91, 91, 0], False),
+        ([91, 91, 0, 91, 0, 91, 91, 91, 91, 91, 91, 91, 91, 91, 91, 91], True),
+        ([0, 61, 0, 0, 61, 61, 61, 61, 61, 61, 61, 61, 61, 61, 61, 0], False),
+        ([0, 0, 0, 91, 0, 91, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0], True),
+        ([0, 91, 0, 0, 0, 0, 0, 0, 0, 0, 0, 91, 91, 91, 91, 0], False),
+    ]
+    for pts, want in cases:
+        assert oracle.check_sequential12(pts, 30, 90) == want
+        assert oracle.ring_run12(pts, 30, 90) == want
+
+
+def test_sequential12_equals_run_of_12_on_all_patterns(oracle):
+    # all 3^16 bright/dark/neither rings: the literal scan == "circular run >= 12", and the
+    # three-of-four pretest never rejects a ring that has such a run
+    assert oracle.fast_selfcheck() == 0
+
+
+def test_three_of_four(oracle):
+    # Features.cpp:477-517 with pb = 130, p_b = 70
+    assert not oracle.three_of_four(100, 200, 100, 200, 130, 70)   # i1 and i9 inside the band
+    assert not oracle.three_of_four(200, 100, 200, 100, 130, 70)   # i5 and i13 inside the band
+    assert oracle.three_of_four(200, 200, 200, 100, 130, 70)
+    assert oracle.three_of_four(10, 10, 100, 10, 130, 70)
+    assert not oracle.three_of_four(200, 200, 10, 10, 130, 70)
+    assert not oracle.three_of_four(130, 131, 131, 70, 130, 70)    # equal to a threshold is neither
+
+
+def test_fast_features_hand_image(oracle):
+    # an isolated bright pixel on black: its whole ring is darker than p - t -> corner; every
+    # other pixel sees at most one bright ring point -> not a corner
+    img = np.zeros((24, 30), np.uint8)
+    img[12, 20] = 200
+    img[5, 7] = 200
+    img[2, 2] = 200      # inside the 3-pixel border: never reported (Features.cpp:414-416)
+    xy = oracle.fast_features(img, 30)
+    assert [(int(x), int(y)) for x, y in xy] == [(7, 5), (20, 12)]   # raster order, p = (x, y)
+    assert len(oracle.fast_features(img, 200)) == 0                   # 0 < 200 - 200 is false
+    # the corner pixel of a bright square is NOT a FAST-12 corner: only 11 ring points are dark
+    sq = np.zeros((24, 24), np.uint8)
+    sq[8:17, 8:17] = 200
+    got = {(int(x), int(y)) for x, y in oracle.fast_features(sq, 30)}
+    assert (8, 8) not in got
+    # flat image: nothing
+    assert len(oracle.fast_features(np.full((20, 20), 90, np.uint8), 30)) == 0
