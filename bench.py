@@ -13,7 +13,9 @@ pair (pair sharding, no data-path collective), so scaling is weak.
 The JSON line also carries the roofline of the dominant kernel, the CPU
 baseline (oracle restatement on a bounded sample, rank 0 at N=1 only) and an
 "extra" object with the other kernels of the path (reference-mode scan,
-rectification warp, descriptor matching), each measured with HIP events.
+rectification warp, FAST-12, descriptor matching) and their CPU timings.  With
+N > 1 the matching leg shards list1 over the ranks (strong scaling of the one
+200k x 200k job); the other extras run at N = 1 only.
 """
 import argparse
 import json
@@ -176,9 +178,10 @@ def main():
         "hbm_GBps_algorithmic": 3.0 * W * H / (kernel_ms * 1e-3) / 1e9,
     }
 
-    # ---- secondary kernels (rank 0 only, outside the timed region) -----------
+    # ---- secondary kernels (outside the timed region) ------------------------
     extra = {}
-    if rank == 0 and not args.no_extra:
+    single = world == 1 and not args.no_extra
+    if single:
         ks, kw = max(3, args.steps // 4), 1
         # reference mode: 1x1 window, whole-row search (bit-exact vs the reference)
         ms = event_time_ms(torch, lambda: ctx.disparity_dev(d_l, d_r, d_o, win=1, max_disp=0), ks, kw)
@@ -200,7 +203,8 @@ def main():
         }
         # rectification warp: batch of 8 x 1080p
         nimg, rh, rw = 8, 1080, 1920
-        src = torch.from_numpy(np.stack([synth.texture(70 + k, rh, rw) for k in range(2)])).cuda()
+        src_np = np.stack([synth.texture(70 + k, rh, rw) for k in range(2)])
+        src = torch.from_numpy(src_np).cuda()
         src = src.repeat(nimg // 2, 1, 1).contiguous()
         dstt = torch.zeros_like(src)
         Hinv = np.stack([ctx.invert_homography(synth.homography(80 + k, rw, rh)).reshape(9)
@@ -211,41 +215,86 @@ def main():
             "workload": "%d x %dx%d u8, K R K^-1 homographies, zero-initialised destination" % (nimg, rw, rh),
             "ms": ms, "Mpix_per_s": nimg * rh * rw / (ms * 1e-3) / 1e6,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "bytes_per_pixel": 2},
+                         "frac": gbs / HBM_PEAK_GBS, "bytes_per_pixel": 2,
+                         "note": "exact fp32 op order incl. two IEEE divides per pixel: the kernel is "
+                                 "VALU-issue bound (~85 instructions/pixel), not HBM bound"},
         }
-        # descriptor matching
+        # FAST-12 corner detection on the left image of the headline pair
+        xy = torch.empty((W * H // 4, 2), dtype=torch.float32, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ms = event_time_ms(torch, lambda: ctx.fast_detect_dev(d_l, xy, cnt, api.FAST_THRESHOLD), ks, kw)
+        gbs = 1.0 * W * H / (ms * 1e-3) / 1e9
+        extra["fast12"] = {
+            "workload": "%dx%d u8, threshold %d, corners compacted in raster order" % (W, H, api.FAST_THRESHOLD),
+            "ms": ms, "Mpix_per_s": W * H / (ms * 1e-3) / 1e6, "corners": int(cnt.item()),
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "bytes_per_pixel": 1},
+        }
+    if not args.no_extra:
+        # descriptor matching (BASELINE config 5).  With N > 1 ranks list1's queries are sharded
+        # (list2 replicated, no data-path collective): strong scaling of the one 200k x 200k job.
+        from stereo_amd.dist import shard_range
         n = args.match_n
         d1, s1, d2, s2 = synth.descriptor_sets(42, n, n)
-        td1, ts1 = torch.from_numpy(d1).cuda(), torch.from_numpy(s1).cuda()
+        lo, hi = shard_range(n, rank, world)
+        nq = hi - lo
+        td1, ts1 = torch.from_numpy(d1[lo:hi]).cuda(), torch.from_numpy(s1[lo:hi]).cuda()
         td2, ts2 = torch.from_numpy(d2).cuda(), torch.from_numpy(s2).cuda()
-        oc = torch.empty(n, dtype=torch.int32, device="cuda")
-        os_ = torch.empty(n, dtype=torch.int32, device="cuda")
-        om = torch.empty(n, dtype=torch.float32, device="cuda")
-        od = torch.empty(n, dtype=torch.float32, device="cuda")
-        ot = torch.empty(n, dtype=torch.uint8, device="cuda")
-        ms = event_time_ms(torch, lambda: ctx.match_dev(td1, ts1, td2, ts2, 1000.0, oc, os_, om, od, ot), 2, 1)
+        oc = torch.empty(nq, dtype=torch.int32, device="cuda")
+        os_ = torch.empty(nq, dtype=torch.int32, device="cuda")
+        om = torch.empty(nq, dtype=torch.float32, device="cuda")
+        od = torch.empty(nq, dtype=torch.float32, device="cuda")
+        ot = torch.empty(nq, dtype=torch.uint8, device="cuda")
+
+        def mstep():
+            ctx.match_dev(td1, ts1, td2, ts2, 1000.0, oc, os_, om, od, ot)
+
+        msteps = 3
+        mstep()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(msteps):
+            mstep()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        mel = time.perf_counter() - t0
+        acc = torch.tensor([float((ot == 3).sum().item())], device=red_dev, dtype=torch.float64)
+        if world > 1:
+            t = torch.tensor([mel], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(acc)
+            mel = float(t.item())
+        ms = mel / msteps * 1e3
         flops = 2.0 * n * n * 128
         # the prefilter takes each fp32 dot product as 3 bf16 MFMA products (hi.hi + hi.lo + lo.hi)
         mfma_flops = 3.0 * flops
         extra["match"] = {
             "workload": "BASELINE config 5: %d x %d 128-d fp32 SIFT-like descriptors, bf16x3 MFMA prefilter "
-                        "+ exact replay (bit-exact indices)" % (n, n),
+                        "+ exact replay (bit-exact indices); list1 sharded over %d GPU(s)" % (n, n, world),
+            "n_gpus": world, "scaling": "strong",
             "ms": ms, "matched_descriptors_per_s": n / (ms * 1e-3),
             "pair_evaluations_per_s": float(n) * n / (ms * 1e-3),
-            "accepted": int((ot == 3).sum().item()),
-            "roofline": {"bound": "mfma", "achieved": mfma_flops / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": mfma_flops / (ms * 1e-3) / 1e12 / MFMA_BF16_TFLOPS,
+            "accepted": int(acc.item()),
+            "roofline": {"bound": "mfma", "achieved": mfma_flops / (ms * 1e-3) / 1e12 / world,
+                         "peak": MFMA_BF16_TFLOPS,
+                         "unit": "TFLOP/s per GPU",
+                         "frac": mfma_flops / (ms * 1e-3) / 1e12 / MFMA_BF16_TFLOPS / world,
                          "dtype": "bf16 (3 products per fp32 product)",
                          "algorithmic_TFLOPs": flops / (ms * 1e-3) / 1e12,
                          "note": "whole call: prep + prefilter + replay + overflow pass"},
         }
-    if extra:
+    if extra and rank == 0:
         out["extra"] = extra
 
     # ---- CPU baseline: the oracle restatement on a bounded sample ------------
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import oracle as orc
-        rows = 480
+        rows = H  # the whole pair: ~4 s of single-thread work
         band_l, band_r = left[:rows], right[:rows]
         t0 = time.perf_counter()
         ref = orc.disparity_ext(band_l, band_r, WIN, D, 0, sliding=True)
@@ -259,10 +308,52 @@ def main():
             "unit": "Mpix*disp/s",
             "cores": 1,
             "kind": "port",
-            "sample": "oracle_disparity_ext_sliding on the first %d of %d rows of the same pair "
+            "sample": "oracle_disparity_ext_sliding on %d of %d rows of the same pair "
                       "(%.1f s, single thread; the reference is single-threaded)" % (rows, H, dt),
             "matches_gpu_on_sample": same,
         }
+
+        if not args.no_extra:
+            # all host cores: row bands with halo on a thread pool (ctypes releases the GIL)
+            from concurrent.futures import ThreadPoolExecutor
+            cores = max(1, min(16, os.cpu_count() or 1))
+            mt_rows = H
+            halo = WIN // 2
+
+            def band(k):
+                lo, hi = k * mt_rows // cores, (k + 1) * mt_rows // cores
+                b0, b1 = max(0, lo - halo), min(H, hi + halo)
+                r = orc.disparity_ext(left[b0:b1], right[b0:b1], WIN, D, 0, sliding=True)
+                return r[lo - b0:hi - b0]
+
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                parts = list(ex.map(band, range(cores)))
+            dt_mt = time.perf_counter() - t0
+            same_mt = bool((np.concatenate(parts)[:mt_rows - halo] == d_o[:mt_rows - halo].cpu().numpy()).all())
+            out["extra"]["cpu_disparity_all_cores"] = {
+                "value": units_evaluated(W, mt_rows, D) / dt_mt / 1e6, "unit": "Mpix*disp/s", "cores": cores,
+                "sample": "first %d rows in %d row bands with halo, one thread each (%.1f s)" % (mt_rows, cores, dt_mt),
+                "matches_gpu_on_sample": same_mt}
+            # matching: oracle_match on a slice of list1 against the whole list2
+            nq_cpu = max(1, min(n, int(2.0e8 // max(n, 1))))
+            t0 = time.perf_counter()
+            cm = orc.match(d1[:nq_cpu], s1[:nq_cpu], d2, s2, 1000.0)
+            dt_m = time.perf_counter() - t0
+            same_m = bool((cm[0] == oc[:nq_cpu].cpu().numpy()).all() and (cm[4] == ot[:nq_cpu].cpu().numpy()).all())
+            out["extra"]["cpu_match"] = {
+                "value": nq_cpu / dt_m, "unit": "matched descriptors/s", "cores": 1,
+                "sample": "oracle_match, first %d queries x %d (%.1f s, single thread, no per-distance "
+                          "heap allocation)" % (nq_cpu, n, dt_m),
+                "matches_gpu_on_sample": same_m}
+            # rectification: oracle_rectify on one image of the batch
+            t0 = time.perf_counter()
+            cr = orc.rectify(src_np[0], np.zeros((rh, rw), np.uint8), Hinv[0].reshape(3, 3))
+            dt_r = time.perf_counter() - t0
+            out["extra"]["cpu_rectify"] = {
+                "value": rh * rw / dt_r / 1e6, "unit": "Mpix/s", "cores": 1,
+                "sample": "oracle_rectify, one %dx%d image (%.2f s, single thread, inverse hoisted)" % (rw, rh, dt_r),
+                "matches_gpu_on_sample": bool((cr == dstt[0].cpu().numpy()).all())}
 
     if rank == 0:
         print(json.dumps(out))

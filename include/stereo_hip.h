@@ -142,6 +142,14 @@ int stx_rectify_u8_dev(stx_ctx *ctx, const uint8_t *d_src, int src_w, int src_h,
                        size_t dst_image_stride, const float *Hinv, int n_images,
                        int flags);
 
+/* Row-band form for sharding one warp over several GPUs: fills
+ * destination rows [dst_row0, dst_row0+dst_rows) of the image RectifyImage iterates over
+ * (Stereography.cpp:612-613); d_dst points at row dst_row0.  The whole source must be
+ * resident (every rank holds its own copy).  Asynchronous. */
+int stx_rectify_rowband_u8_dev(stx_ctx *ctx, const uint8_t *d_src, int src_w, int src_h,
+                               size_t src_stride, uint8_t *d_dst, int dst_w, int dst_row0,
+                               int dst_rows, size_t dst_stride, const float Hinv[9], int flags);
+
 /* ---- D: dense disparity scan -------------------------------------------
  * Replaces ComputeDepthImage (Stereography.h:53-55).  Reference mode is
  * win = 1, max_disp = 0, cost_mode = STX_COST_SAD: 1x1 absolute difference,

@@ -53,6 +53,8 @@ PROTOTYPES = {
     "stx_rectify_u8_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
                                      _vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, _f32p,
                                      C.c_int, C.c_int]),
+    "stx_rectify_rowband_u8_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_int,
+                                             C.c_int, C.c_int, C.c_size_t, _f32p, C.c_int]),
     "stx_disparity_u8": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_size_t, C.c_int,
                                    C.c_int, C.c_int, _vp, C.c_size_t]),
     "stx_disparity_u16": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_size_t, C.c_int,

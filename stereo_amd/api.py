@@ -152,6 +152,16 @@ class Context:
             int(d3.stride(1)), int(d3.stride(0)), Hinv.ctypes.data_as(C.POINTER(C.c_float)), n,
             int(flags)), "stx_rectify_u8_dev")
 
+    def rectify_rowband_dev(self, src, dst_band, dst_row0, Hinv, flags=RECT_PRESERVE_DST):
+        """src: [H,W] uint8 device tensor (whole source); dst_band: [rows,W'] device tensor that
+        receives destination rows [dst_row0, dst_row0+rows)."""
+        Hinv = np.ascontiguousarray(Hinv, np.float32).reshape(9)
+        check(self._lib.stx_rectify_rowband_u8_dev(
+            self._h, src.data_ptr(), int(src.shape[1]), int(src.shape[0]), int(src.stride(0)),
+            dst_band.data_ptr(), int(dst_band.shape[1]), int(dst_row0), int(dst_band.shape[0]),
+            int(dst_band.stride(0)), Hinv.ctypes.data_as(C.POINTER(C.c_float)), int(flags)),
+            "stx_rectify_rowband_u8_dev")
+
     # -- FAST -----------------------------------------------------------------
     def fast_detect(self, img, threshold=FAST_THRESHOLD, max_out=None):
         """(xy float32 [n,2] in raster order, total count)."""

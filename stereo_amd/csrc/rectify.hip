@@ -59,10 +59,10 @@ __device__ __forceinline__ bool rect_pixel(const uint8_t *__restrict__ src, size
 __global__ __launch_bounds__(RECT_THREADS) void rectify_kernel(
     const uint8_t *__restrict__ src, int src_w, int src_h, size_t src_stride,
     size_t src_image_stride, uint8_t *__restrict__ dst, int dst_w, int dst_h, size_t dst_stride,
-    size_t dst_image_stride, const float *__restrict__ hinv, int zero_fill)
+    size_t dst_image_stride, const float *__restrict__ hinv, int zero_fill, int dst_y0)
 {
     const int img = blockIdx.z;
-    const int y = blockIdx.y;
+    const int y = blockIdx.y;  // row of the band held at dst; image row dst_y0 + y
     const int x0 = (blockIdx.x * RECT_THREADS + threadIdx.x) * RECT_PX;
     if (x0 >= dst_w) return;
     float hv[9];
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(RECT_THREADS) void rectify_kernel(
     const uint8_t *s = src + (size_t)img * src_image_stride;
     uint8_t *drow = dst + (size_t)img * dst_image_stride + (size_t)y * dst_stride;
     const float xmax = (float)(src_w - 1), ymax = (float)(src_h - 1);
-    const float py = (float)y;
+    const float py = (float)(dst_y0 + y);
 
     unsigned word = 0, mask = 0;
 #pragma unroll
@@ -108,13 +108,13 @@ __global__ __launch_bounds__(RECT_THREADS) void rectify_kernel(
 int stx_launch_rectify(stx_ctx *ctx, const uint8_t *d_src, int src_w, int src_h,
                        size_t src_stride, size_t src_image_stride, uint8_t *d_dst, int dst_w,
                        int dst_h, size_t dst_stride, size_t dst_image_stride,
-                       const float *d_hinv, int n_images, int flags)
+                       const float *d_hinv, int n_images, int flags, int dst_y0)
 {
     if (dst_w <= 0 || dst_h <= 0 || n_images <= 0) return STX_OK;
     if (dst_h > 65535 || n_images > 65535) return STX_ERR_TOO_LARGE;
     dim3 grid((dst_w + RECT_THREADS * RECT_PX - 1) / (RECT_THREADS * RECT_PX), dst_h, n_images);
     hipLaunchKernelGGL(rectify_kernel, grid, dim3(RECT_THREADS), 0, ctx->stream, d_src, src_w,
                        src_h, src_stride, src_image_stride, d_dst, dst_w, dst_h, dst_stride,
-                       dst_image_stride, d_hinv, flags == STX_RECT_DST_IS_ZERO ? 1 : 0);
+                       dst_image_stride, d_hinv, flags == STX_RECT_DST_IS_ZERO ? 1 : 0, dst_y0);
     return (int)hipGetLastError();
 }

@@ -259,6 +259,28 @@ extern "C" int stx_rectify_u8_dev(stx_ctx *ctx, const uint8_t *d_src, int src_w,
                               dst_w, dst_h, dst_stride, dst_image_stride, d_hinv, n_images, flags);
 }
 
+extern "C" int stx_rectify_rowband_u8_dev(stx_ctx *ctx, const uint8_t *d_src, int src_w, int src_h,
+                                          size_t src_stride, uint8_t *d_dst, int dst_w, int dst_row0,
+                                          int dst_rows, size_t dst_stride, const float Hinv[9],
+                                          int flags)
+{
+    if (!ctx || !Hinv || dst_row0 < 0) return STX_ERR_INVALID_ARG;
+    if (flags != STX_RECT_PRESERVE_DST && flags != STX_RECT_DST_IS_ZERO) return STX_ERR_INVALID_ARG;
+    int rc = check_image(d_src, src_w, src_h, src_stride);
+    if (rc) return rc;
+    rc = check_image(d_dst, dst_w, dst_rows, dst_stride);
+    if (rc) return rc;
+    if ((long long)dst_row0 + dst_rows > (1ll << 24)) return STX_ERR_TOO_LARGE;  // (float)y exact
+    STX_HIP(hipSetDevice(ctx->device));
+    if (dst_w == 0 || dst_rows == 0) return STX_OK;
+    int err;
+    float *d_hinv = (float *)stx_workspace(ctx, STX_SLOT_HINV, sizeof(float) * 9, &err);
+    if (!d_hinv) return err;
+    STX_HIP(hipMemcpyAsync(d_hinv, Hinv, sizeof(float) * 9, hipMemcpyHostToDevice, ctx->stream));
+    return stx_launch_rectify(ctx, d_src, src_w, src_h, src_stride, 0, d_dst, dst_w, dst_rows,
+                              dst_stride, 0, d_hinv, 1, flags, dst_row0);
+}
+
 extern "C" int stx_rectify_u8(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h,
                               size_t src_stride, uint8_t *dst, int dst_w, int dst_h,
                               size_t dst_stride, const float Hinv[9], int flags)

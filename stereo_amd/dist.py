@@ -88,3 +88,39 @@ def disparity_pairs(compute_pairs, n_pairs, group=None):
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lo, hi = shard_range(n_pairs, rank, world)
     return lo, hi, compute_pairs(lo, hi)
+
+
+def rectify_rowbands(compute_band, dst_h, group=None, gather=True):
+    """Row-band sharded warp of ONE image whose source every rank holds.
+
+    compute_band(row0, rows) -> [rows, W] tensor with destination rows [row0, row0+rows).
+    The warp is output-pixel-local, so there is no halo and no exchange; with gather=True the
+    bands are collected on rank 0 (None elsewhere), else each rank keeps its band (the case
+    where the band feeds this rank's disparity band directly)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    row0, row1 = shard_range(dst_h, rank, world)
+    out = compute_band(row0, row1 - row0)
+    if not gather or world == 1:
+        return out
+    counts = [shard_range(dst_h, r, world)[1] - shard_range(dst_h, r, world)[0] for r in range(world)]
+    return gather_rows(out, counts, 0, group)
+
+
+def match_sharded(compute_queries, n1, group=None, gather=True):
+    """Query-sharded matching: rank r matches list1 rows
+    shard_range(n1, r, world) against the whole (replicated) list2.
+
+    compute_queries(lo, hi) -> tuple of per-query tensors of length hi-lo (closest, second,
+    min_dist, second_dist, status).  Queries are independent, so the per-rank results are simply
+    the rows [lo, hi) of the single-GPU result; gather=True concatenates them on rank 0 in list1
+    order (the order the reference emits its pairs in, Features.cpp:1028), None elsewhere."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_range(n1, rank, world)
+    parts = compute_queries(lo, hi)
+    if not gather or world == 1:
+        return parts
+    counts = [shard_range(n1, r, world)[1] - shard_range(n1, r, world)[0] for r in range(world)]
+    res = [gather_rows(p, counts, 0, group) for p in parts]
+    return tuple(res) if rank == 0 else None

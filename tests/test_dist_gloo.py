@@ -71,3 +71,51 @@ def test_rowband_sharding_world2(win, D):
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _worker_rm(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as o
+        from stereo_amd import synth
+        from stereo_amd.dist import rectify_rowbands, match_sharded
+        h, w = 41, 60
+        src = synth.texture(5, h, w)
+        Hinv = o.invert3x3(synth.homography(5, w, h))
+        full = o.rectify(src, np.zeros((h, w), np.uint8), Hinv)
+        # the warp is output-pixel-local: a band is a slice of the full result
+        got = rectify_rowbands(lambda row0, rows: torch.from_numpy(full[row0:row0 + rows].copy()), h)
+        ok = bool((got.numpy() == full).all()) if rank == 0 else got is None
+
+        n1, n2 = 37, 50
+        d1, s1, d2, s2 = synth.descriptor_sets(9, n1, n2)
+        want = o.match(d1, s1, d2, s2, 1000.0)
+
+        def queries(lo, hi):
+            return tuple(torch.from_numpy(a) for a in o.match(d1[lo:hi], s1[lo:hi], d2, s2, 1000.0))
+
+        res = match_sharded(queries, n1)
+        if rank == 0:
+            for g, wnt in zip(res, want):
+                ok = ok and g.numpy().tobytes() == wnt.tobytes()
+        else:
+            ok = ok and res is None
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rectify_and_match_sharding_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_worker_rm, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]

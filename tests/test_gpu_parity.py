@@ -351,6 +351,41 @@ def test_rectify_dev_batch_full_size(ctx, oracle):
         assert (d[k].cpu().numpy() == want).all()
 
 
+def test_rectify_rowbands_feed_disparity_rowbands(ctx, oracle):
+    """three 'ranks' each warp their destination band (plus the
+    disparity halo) of both images and scan their band; the stitched result equals the
+    single-GPU pipeline."""
+    import torch
+    from stereo_amd.dist import row_band
+    h, w, win, D = 101, 200, 5, 32
+    a, b = synth.texture(21, h, w), synth.texture(22, h, w)
+    i0 = oracle.invert3x3(synth.homography(5, w, h, deg_y=1.0))
+    i1 = oracle.invert3x3(synth.homography(6, w, h, deg_y=-1.0))
+    r0 = oracle.rectify(a, np.zeros((h, w), np.uint8), i0)
+    r1 = oracle.rectify(b, np.zeros((h, w), np.uint8), i1)
+    want = oracle.disparity_ext(r0, r1, win, D, 0)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        world = 3
+        out = torch.full((h, w), 77, dtype=torch.uint8, device="cuda")
+        for rank in range(world):
+            row0, rows, b0, bh = row_band(h, rank, world, win // 2)
+            band0 = torch.full((bh, w), 9, dtype=torch.uint8, device="cuda")
+            band1 = torch.zeros((bh, w), dtype=torch.uint8, device="cuda")
+            ctx.rectify_rowband_dev(ta, band0, b0, i0, api.RECT_DST_IS_ZERO)
+            ctx.rectify_rowband_dev(tb, band1, b0, i1, api.RECT_PRESERVE_DST)
+            torch.cuda.synchronize()
+            assert (band0.cpu().numpy() == r0[b0:b0 + bh]).all()
+            assert (band1.cpu().numpy() == r1[b0:b0 + bh]).all()
+            ctx.disparity_rowband_dev(band0, band1, b0, h, row0, rows, out[row0:row0 + rows],
+                                      win=win, max_disp=D)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_stream(0)
+    assert (out.cpu().numpy() == want).all()
+
+
 def test_rectify_then_disparity_fused(ctx, oracle):
     """main.cpp:362-380 (rectify both, then scan) without leaving the GPU."""
     h, w = 120, 333
@@ -470,6 +505,21 @@ def test_match_properties_large(ctx, oracle):
     far = np.zeros((1, 128), np.float32); far[0, 0] = 50.0
     ga = ctx.match(d1, s1, np.concatenate([d2, far]), np.concatenate([s2, [0]]).astype(np.float32), 1000.0)
     _match_equal(ga, got)
+
+
+def test_match_query_shards_concatenate(ctx, oracle):
+    """list1 sharded over 3 'ranks', list2 replicated; the shards'
+    outputs concatenated in list1 order are the single-GPU result."""
+    from stereo_amd.dist import shard_range
+    n1, n2 = 1000, 1500
+    d1, s1, d2, s2 = synth.descriptor_sets(77, n1, n2)
+    want = oracle.match(d1, s1, d2, s2, 1000.0)
+    parts = []
+    for rank in range(3):
+        lo, hi = shard_range(n1, rank, 3)
+        parts.append(ctx.match(d1[lo:hi], s1[lo:hi], d2, s2, 1000.0))
+    got = tuple(np.concatenate([p[k] for p in parts]) for k in range(5))
+    _match_equal(got, want)
 
 
 def test_match_descriptors_reference_signature(ctx, oracle):
