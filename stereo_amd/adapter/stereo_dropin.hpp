@@ -1,5 +1,5 @@
-// stereo_dropin.hpp -- the reference's three hot-path functions, re-implemented on
-// top of libstereo_hip.so.  Header-only; include it INSTEAD of the bodies at
+// stereo_dropin.hpp -- the reference's three hot-path functions (and FindFASTFeatures,
+// stereo/Features.cpp:407-471), re-implemented on top of libstereo_hip.so.  Header-only; include it INSTEAD of the bodies at
 //   stereo/Features.cpp:1020-1079      (MatchDescriptors)
 //   stereo/Stereography.cpp:596-631    (RectifyImage)
 //   stereo/Stereography.cpp:649-691    (ComputeDepthImage)
@@ -76,6 +76,32 @@ inline std::vector<std::pair<Feature, Feature> > MatchDescriptors(
         matches.push_back(std::make_pair(list1[i], list2[closest[i]]));
     }
     return matches;
+}
+
+// Features.h:167-169 (body Features.cpp:407-471).  Appends one default-constructed Feature per
+// corner with p = (x, y), in the reference's raster order; always returns true.
+inline bool FindFASTFeatures(cv::Mat img, std::vector<Feature> &features)
+{
+    using namespace stereo_hip_dropin;
+    if (img.cols <= 0 || img.rows <= 0) return true;
+    int count = 0;
+    std::vector<float> xy(2 * 65536);
+    check(stx_fast_detect_u8(context(), img.data, img.cols, img.rows, (size_t)img.step, 30 /* FAST_THRESHOLD */,
+                             xy.data(), (int)(xy.size() / 2), &count),
+          "stx_fast_detect_u8");
+    if ((size_t)count > xy.size() / 2) {  // more corners than the first guess: ask again with room for all
+        xy.resize(2 * (size_t)count);
+        check(stx_fast_detect_u8(context(), img.data, img.cols, img.rows, (size_t)img.step, 30, xy.data(), count,
+                                 &count),
+              "stx_fast_detect_u8");
+    }
+    for (int i = 0; i < count; ++i) {
+        Feature feature;
+        feature.p.x = xy[2 * (size_t)i];
+        feature.p.y = xy[2 * (size_t)i + 1];
+        features.push_back(feature);
+    }
+    return true;
 }
 
 // Stereography.h:48-51.  H is the forward homography; `rectified` is in/out.

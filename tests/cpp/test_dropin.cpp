@@ -1,4 +1,4 @@
-// Drives the three reference signatures of stereo_dropin.hpp on a GPU and compares
+// Drives the reference signatures of stereo_dropin.hpp on a GPU and compares
 // with the CPU oracle (test infrastructure).  Built and run by tests/test_gpu_dropin.py.
 #include <opencv2/core.hpp>
 #include <Eigen/Dense>
@@ -106,6 +106,23 @@ int main()
         if (cap.str() != wantlog) ++fails;
         if (l1[0].distFromBestMatch != 0) ++fails;  // caller's lists untouched
         std::printf("M fails so far: %d (pairs %zu, oracle %d)\n", fails, pairs.size(), acc);
+    }
+    // ---- FAST ------------------------------------------------------------------
+    {
+        const int w = 150, h = 70;
+        cv::Mat img(h, w, 160);
+        for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x)
+            img.at<uint8_t>(y, x) = (uint8_t)(((x / 9 + y / 7) % 2) ? 200 : 40 + rnd() % 8);
+        std::vector<Feature> feats(1);
+        feats[0].p.x = -1.f;
+        if (!FindFASTFeatures(img, feats)) ++fails;
+        std::vector<float> want(2 * (size_t)w * h);
+        const int n = oracle_fast_features(img.data, w, h, img.step, 30, want.data(), w * h);
+        if ((int)feats.size() != n + 1 || feats[0].p.x != -1.f) ++fails;
+        for (int i = 0; i < n && i + 1 < (int)feats.size(); ++i)
+            if (feats[i + 1].p.x != want[2 * i] || feats[i + 1].p.y != want[2 * i + 1]) ++fails;
+        if (n < 10) ++fails;
+        std::printf("FAST fails so far: %d (corners %d)\n", fails, n);
     }
     std::printf(fails ? "DROPIN FAIL\n" : "DROPIN OK\n");
     return fails ? 1 : 0;
