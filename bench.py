@@ -201,6 +201,47 @@ def main():
                          "peak": VALU_LANEOPS / 1e12, "unit": "Tlane-op/s",
                          "frac": units * OPS_PER_UNIT_WIN1 / (ms * 1e-3) / VALU_LANEOPS},
         }
+        ms = event_time_ms(torch, lambda: ctx.disparity_dev(d_l, d_r, d_o, win=WIN, max_disp=D,
+                                                            cost_mode=api.COST_SSD), ks, kw)
+        extra["disparity_ssd_9x9_d256"] = {
+            "workload": "%dx%d, %dx%d SSD window, %d disparities (same sliding-sum kernel, squared taps)" % (W, H, WIN, WIN, D),
+            "ms": ms, "Mpix_disp_per_s": units / (ms * 1e-3) / 1e6,
+            "roofline": {"bound": "valu", "achieved": units * OPS_PER_UNIT_WINDOWED / (ms * 1e-3) / 1e12,
+                         "peak": VALU_LANEOPS / 1e12, "unit": "Tlane-op/s",
+                         "frac": units * OPS_PER_UNIT_WINDOWED / (ms * 1e-3) / VALU_LANEOPS},
+        }
+        # BASELINE config 3: one 4K pair, 512 disparities (two passes, u16 output)
+        w3, h3, D3 = 3840, 2160, 512
+        l3, r3 = synth.rectified_pair(303, h3, w3, D3)
+        t_l3, t_r3 = torch.from_numpy(l3).cuda(), torch.from_numpy(r3).cuda()
+        t_o3 = torch.empty((h3, w3), dtype=torch.int16, device="cuda")
+        ms = event_time_ms(torch, lambda: ctx.disparity_dev(t_l3, t_r3, t_o3, win=WIN, max_disp=D3), ks, kw)
+        u3 = units_evaluated(w3, h3, D3)
+        extra["disparity_config3_4k_d512"] = {
+            "workload": "BASELINE config 3 on one GPU: %dx%d, %dx%d SAD, %d disparities, u16 output" % (w3, h3, WIN, WIN, D3),
+            "ms": ms, "Mpix_disp_per_s": u3 / (ms * 1e-3) / 1e6,
+            "roofline": {"bound": "valu", "achieved": u3 * OPS_PER_UNIT_WINDOWED / (ms * 1e-3) / 1e12,
+                         "peak": VALU_LANEOPS / 1e12, "unit": "Tlane-op/s",
+                         "frac": u3 * OPS_PER_UNIT_WINDOWED / (ms * 1e-3) / VALU_LANEOPS},
+        }
+        del t_l3, t_r3, t_o3
+        # BASELINE config 4: batch of 1024 1080p pairs, 192 disparities, one batched launch
+        w4, h4, D4, n4 = 1920, 1080, 192, 1024
+        p4 = [synth.rectified_pair(400 + k, h4, w4, D4) for k in range(4)]
+        t_l4 = torch.from_numpy(np.stack([p[0] for p in p4])).cuda().repeat(n4 // 4, 1, 1)
+        t_r4 = torch.from_numpy(np.stack([p[1] for p in p4])).cuda().repeat(n4 // 4, 1, 1)
+        t_o4 = torch.empty_like(t_l4)
+        ms = event_time_ms(torch, lambda: ctx.disparity_dev(t_l4, t_r4, t_o4, win=WIN, max_disp=D4), 2, 1)
+        u4 = units_evaluated(w4, h4, D4) * n4
+        extra["disparity_config4_batch1024"] = {
+            "workload": "BASELINE config 4 on one GPU: %d x %dx%d pairs (4 distinct, repeated), %dx%d SAD, "
+                        "%d disparities, one batched launch" % (n4, w4, h4, WIN, WIN, D4),
+            "ms": ms, "pairs_per_s": n4 / (ms * 1e-3), "Mpix_disp_per_s": u4 / (ms * 1e-3) / 1e6,
+            "roofline": {"bound": "valu", "achieved": u4 * OPS_PER_UNIT_WINDOWED / (ms * 1e-3) / 1e12,
+                         "peak": VALU_LANEOPS / 1e12, "unit": "Tlane-op/s",
+                         "frac": u4 * OPS_PER_UNIT_WINDOWED / (ms * 1e-3) / VALU_LANEOPS},
+        }
+        del t_l4, t_r4, t_o4
         # rectification warp: batch of 8 x 1080p
         nimg, rh, rw = 8, 1080, 1920
         src_np = np.stack([synth.texture(70 + k, rh, rw) for k in range(2)])

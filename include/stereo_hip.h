@@ -67,7 +67,7 @@ extern "C" {
 #define STX_MATCH_MFMA_BF16 3 /* same with the dot products as 3 bf16 MFMA products (hi/lo split) */
 
 /* disparity kernel selector (stx_set_disparity_algo) */
-#define STX_DISP_AUTO 0       /* sliding-sum kernel where it applies (SAD, win <= 9), else tap-by-tap */
+#define STX_DISP_AUTO 0       /* sliding-sum kernel where it applies (win <= 9), else tap-by-tap */
 #define STX_DISP_BRUTEFORCE 1 /* tap-by-tap kernel for every D1-ext call */
 
 typedef struct stx_ctx stx_ctx;

@@ -262,6 +262,20 @@ __device__ __forceinline__ unsigned min3_u32(unsigned a, unsigned b, unsigned c)
     return r;
 }
 
+// t*t + c and t*t for t < 2^24 (one instruction each)
+__device__ __forceinline__ unsigned sq_acc_u24(unsigned t, unsigned c)
+{
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %1, %2" : "=v"(r) : "v"(t), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned sq_u24(unsigned t)
+{
+    unsigned r;
+    asm("v_mul_u32_u24 %0, %1, %1" : "=v"(r) : "v"(t));
+    return r;
+}
+
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // One ds_read_b128.  The empty asm keeps the 16-byte load whole: without it the
@@ -301,9 +315,19 @@ struct BandArgs {
     int out_bytes;
 };
 
-template <int R>
+// SSD variant: a tap costs (a-b)^2 <= 65025, a 9x9 window < 2^23, so the key is
+// (cost << 8) | (255 - (d - dbase)) with a pass-local disparity code; pixels are pre-shifted by
+// 4 bits so that |a-b|^2 (v_sad_u32, v_mad_u32_u24) is born shifted by 8.  Invalid candidates
+// and disparities past D set bit 31 (OR, so the two cannot wrap); passes are merged on the
+// cost field alone (a later pass holds larger d and wins ties).
+template <int R, bool SSD>
 __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs a)
 {
+    constexpr unsigned SH = SSD ? 8u : BAND_SH;      // key = cost << SH | code
+    constexpr unsigned PSH = SSD ? 4u : BAND_SH;     // pixel pre-shift in the ring
+    constexpr unsigned LOW = (1u << SH) - 1;
+    constexpr unsigned PAST_D = SSD ? BAND_MASKED : BAND_PAST_D;
+    constexpr unsigned INIT = SSD ? 0x7FFFFFFFu : BAND_INIT;
     constexpr int WIN = 2 * R + 1;
     constexpr int HL = (R + 3) / 4;  // halo lanes on each side of the tile
     constexpr int TILE_OUT = BAND_COLS - 8 * HL;
@@ -337,7 +361,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     // this lane's first img1 word: column x0 + 4*lane - dB - 16
     const int roff4 = lane + (BAND_ND / 4) * (nw - 1 - wave);
 
-    for (int i = tid; i < 2 * BAND_COLS; i += blockDim.x) best[i] = BAND_INIT;
+    for (int i = tid; i < 2 * BAND_COLS; i += blockDim.x) best[i] = INIT;
 
     // ---- ring fill: one image row -> slot ---------------------------------
     // each thread carries at most FILL_MAX words between its global loads (issued
@@ -359,12 +383,12 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     };
     auto fill_store = [&](int yy) {
         const int slot = (yy + 64) & (BAND_RING - 1);
-        if (tid < BAND_COLS) Lrow[slot * BAND_COLS + tid] = fill_l << BAND_SH;
+        if (tid < BAND_COLS) Lrow[slot * BAND_COLS + tid] = fill_l << PSH;
 #pragma unroll
         for (int k = 0; k < FILL_MAX; ++k) {
             const int i = tid + k * (int)blockDim.x;
             if (i < rw) {
-                Rrow[slot * rw + i] = fill_r[k] << BAND_SH;
+                Rrow[slot * rw + i] = fill_r[k] << PSH;
                 Mrow[slot * rw + i] = fill_r[k] ? 0u : BAND_MASKED;
             }
         }
@@ -382,7 +406,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
         for (int c = 0; c < 4; ++c) carrier[c] = ((x0 + 4 * lane + c + 1024 * WIN) % WIN) == 0;
 #pragma unroll
         for (int dd = 0; dd < BAND_ND; ++dd) {
-            const unsigned code = dB + dd < a.D ? BAND_LOW - (unsigned)(dB + dd) : BAND_PAST_D;
+            const unsigned code = dB + dd < a.D ? LOW - (unsigned)(SSD ? dB + dd - a.dbase : dB + dd) : PAST_D;
 #pragma unroll
             for (int c = 0; c < 4; ++c) V[dd][c] = carrier[c] ? code : 0u;
         }
@@ -413,10 +437,15 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
             for (int dd = 0; dd < BAND_ND; ++dd)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if (R == 0)  // 1x1 window: the sum is one term; V only holds the code
-                        W1[dd][c] = sad_u32(rv[16 + c - dd], lv[c], V[dd][c]);
+                    unsigned sum;
+                    if (SSD)
+                        sum = sq_acc_u24(sad_u32_0(rv[16 + c - dd], lv[c]), V[dd][c]);
                     else
-                        V[dd][c] = sad_u32(rv[16 + c - dd], lv[c], V[dd][c]);
+                        sum = sad_u32(rv[16 + c - dd], lv[c], V[dd][c]);
+                    if (R == 0)  // 1x1 window: the sum is one term; V only holds the code
+                        W1[dd][c] = sum;
+                    else
+                        V[dd][c] = sum;
                 }
         }
         // ---- subtract the row leaving the window ----------------------------
@@ -434,7 +463,10 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
 #pragma unroll
             for (int dd = 0; dd < BAND_ND; ++dd)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) V[dd][c] -= sad_u32_0(rv[16 + c - dd], lv[c]);
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned t = sad_u32_0(rv[16 + c - dd], lv[c]);
+                    V[dd][c] -= SSD ? sq_u24(t) : t;
+                }
         }
 
         // ---- output row y = ys - R: window sums, keys, winner-take-all --------
@@ -487,7 +519,8 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const unsigned key = cost[c] + mv[16 + c - dd];  // mask word: 0 or BAND_MASKED
+                    // mask word: 0 or BAND_MASKED
+                    const unsigned key = SSD ? (cost[c] | mv[16 + c - dd]) : (cost[c] + mv[16 + c - dd]);
                     if (dd & 1)
                         m[c] = min3_u32(m[c], pend[c], key);
                     else
@@ -506,23 +539,34 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
         if (y >= yb && tid < BAND_COLS) {
             const int c = tid;
             unsigned key = best[(y & 1) * BAND_COLS + c];
-            best[(y & 1) * BAND_COLS + c] = BAND_INIT;
+            best[(y & 1) * BAND_COLS + c] = INIT;
             const int x = x0 + c;
             if ((c >> 2) >= HL && (c >> 2) < 64 - HL && x < w) {
                 const size_t pix = (size_t)(y - a.row0) * w + x;
                 unsigned *kp = a.keys ? a.keys + pair * (size_t)a.rows * w + pix : nullptr;
-                if (kp && !a.first_pass) key = min(key, *kp);
-                if (!a.last_pass) {
-                    *kp = key;
+                bool emit;
+                if (SSD) {
+                    // the output array carries the best disparity between passes, keys the best key
+                    emit = true;
+                    if (kp && !a.first_pass) {
+                        const unsigned old = *kp;
+                        emit = key < INIT && (old >= INIT || (key >> SH) <= (old >> SH));
+                    }
+                    if (kp && !a.last_pass && emit) *kp = key;
                 } else {
+                    if (kp && !a.first_pass) key = min(key, *kp);
+                    if (!a.last_pass) *kp = key;
+                    emit = a.last_pass;
+                }
+                if (emit) {
                     const int slot = (y + 64) & (BAND_RING - 1);
                     int v;
                     if (Lrow[slot * BAND_COLS + c] == 0)
                         v = 0;  // centre pixel of img0 is 0: output stays 0
-                    else if (key >= BAND_INIT)
+                    else if (key >= INIT)
                         v = x;  // no valid candidate: xBest stays 0
                     else
-                        v = (int)(BAND_LOW - (key & BAND_LOW));  // d = x - xBest
+                        v = (int)(LOW - (key & LOW)) + (SSD ? a.dbase : 0);  // d = x - xBest
                     uint8_t *orow = a.out + pair * a.out_pair_stride + (size_t)(y - a.row0) * a.out_stride;
                     if (a.out_bytes == 1)
                         orow[x] = (uint8_t)(v & 0xFF);
@@ -534,7 +578,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     }
 }
 
-template <int R>
+template <int R, bool SSD>
 int launch_band(stx_ctx *ctx, BandArgs a, int n_pairs)
 {
     constexpr int HL = (R + 3) / 4;
@@ -574,10 +618,10 @@ int launch_band(stx_ctx *ctx, BandArgs a, int n_pairs)
         a.last_pass = p == npass - 1;
         const int rw = BAND_COLS + BAND_ND * nw;
         const size_t lds = sizeof(unsigned) * ((size_t)BAND_RING * (BAND_COLS + 2 * rw) + 2 * BAND_COLS);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(disp_band_kernel<R>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(disp_band_kernel<R, SSD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(disp_band_kernel<R>, dim3(xt, bands, n_pairs), dim3(64 * nw), lds,
+        hipLaunchKernelGGL((disp_band_kernel<R, SSD>), dim3(xt, bands, n_pairs), dim3(64 * nw), lds,
                            ctx->stream, a);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
@@ -611,18 +655,26 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
 
     const int r = win / 2;
     const int D = max_disp < w ? max_disp : w;  // candidates beyond column 0 do not exist
-    if (cost_mode == STX_COST_SAD && r <= 4 && D <= 4096 && !ctx->force_bruteforce) {
+    if (r <= 4 && D <= 4096 && !ctx->force_bruteforce) {
         BandArgs a;
         a.img0 = d_img0; a.img1 = d_img1; a.w = w; a.h = h; a.stride = stride;
         a.pair_stride = pair_stride; a.row0 = row0; a.rows = rows; a.bh = rows; a.D = D;
         a.dbase = 0; a.keys = nullptr; a.first_pass = 1; a.last_pass = 1; a.out = o;
         a.out_stride = out_stride; a.out_pair_stride = out_pair_stride; a.out_bytes = out_bytes;
+        if (cost_mode == STX_COST_SSD && r > 0) {  // a single tap orders candidates as SAD does
+            switch (r) {
+            case 1: return launch_band<1, true>(ctx, a, n_pairs);
+            case 2: return launch_band<2, true>(ctx, a, n_pairs);
+            case 3: return launch_band<3, true>(ctx, a, n_pairs);
+            default: return launch_band<4, true>(ctx, a, n_pairs);
+            }
+        }
         switch (r) {
-        case 0: return launch_band<0>(ctx, a, n_pairs);
-        case 1: return launch_band<1>(ctx, a, n_pairs);
-        case 2: return launch_band<2>(ctx, a, n_pairs);
-        case 3: return launch_band<3>(ctx, a, n_pairs);
-        default: return launch_band<4>(ctx, a, n_pairs);
+        case 0: return launch_band<0, false>(ctx, a, n_pairs);
+        case 1: return launch_band<1, false>(ctx, a, n_pairs);
+        case 2: return launch_band<2, false>(ctx, a, n_pairs);
+        case 3: return launch_band<3, false>(ctx, a, n_pairs);
+        default: return launch_band<4, false>(ctx, a, n_pairs);
         }
     }
     const size_t lds = (size_t)(EXT_TX + 2 * r) * (EXT_TY + 2 * r) +

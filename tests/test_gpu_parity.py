@@ -111,6 +111,34 @@ def test_disparity_sliding_kernel_tiles_and_passes(ctx, oracle, win, h, w, D):
     assert (got == want).all(), np.argwhere(got != want)[:10]
 
 
+@pytest.mark.parametrize("win", [3, 5, 7, 9])
+@pytest.mark.parametrize("h,w,D", [(40, 300, 16), (60, 520, 100), (33, 777, 256), (25, 1100, 300),
+                                   (20, 900, 700)])
+def test_disparity_sliding_kernel_ssd(ctx, oracle, win, h, w, D):
+    """SSD through the sliding-sum kernel: (a-b)^2 taps, pass-local disparity code, passes
+    merged on the cost field (D > 256), against the oracle and the tap-by-tap kernel."""
+    a, b = _rand_pair(win * 3 + h + w + D, h, w, zero=0.03)
+    dt = np.uint16 if D > 256 else np.uint8
+    want = oracle.disparity_ext(a, b, win, D, 1, dt, sliding=True)
+    got = ctx.disparity(a, b, win=win, max_disp=D, cost_mode=api.COST_SSD, out_dtype=dt)
+    assert (got == want).all(), np.argwhere(got != want)[:10]
+
+
+def test_disparity_ssd_extreme_contrast(ctx, oracle):
+    """Saturated costs: a 9x9 window of |a-b| = 254/255 everywhere (cost close to 65025*81),
+    equal-cost ties across waves and passes, zero centres."""
+    h, w, D = 24, 600, 300
+    a = np.full((h, w), 255, np.uint8)
+    b = np.ones((h, w), np.uint8)
+    a[5, 100] = 0
+    b[7, 50:60] = 0
+    b[:, 300:] = 255                      # exact matches (cost 0) far to the right
+    for cm in (api.COST_SAD, api.COST_SSD):
+        want = oracle.disparity_ext(a, b, 9, D, cm, np.uint16, sliding=True)
+        got = ctx.disparity(a, b, win=9, max_disp=D, cost_mode=cm, out_dtype=np.uint16)
+        assert (got == want).all(), (cm, np.argwhere(got != want)[:10])
+
+
 @pytest.mark.parametrize("h,w,win,D", [(1, 1, 3, 4), (2, 3, 5, 8), (5, 64, 9, 16), (17, 65, 9, 16),
                                        (16, 63, 3, 100), (33, 129, 5, 7)])
 def test_disparity_ext_ragged_sizes(ctx, oracle, h, w, win, D):
