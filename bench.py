@@ -312,10 +312,11 @@ def main():
             mel = float(t.item())
         ms = mel / msteps * 1e3
         flops = 2.0 * n * n * 128
-        # the prefilter takes each fp32 dot product as 3 bf16 MFMA products (hi.hi + hi.lo + lo.hi)
-        mfma_flops = 3.0 * flops
+        # the prefilter takes each fp32 dot product as ONE bf16 MFMA product (hi.hi) under a rigorous
+        # error bound; the exact replay restores bit-exact results
+        mfma_flops = 1.0 * flops
         extra["match"] = {
-            "workload": "BASELINE config 5: %d x %d 128-d fp32 SIFT-like descriptors, bf16x3 MFMA prefilter "
+            "workload": "BASELINE config 5: %d x %d 128-d fp32 SIFT-like descriptors, bf16 MFMA prefilter "
                         "+ exact replay (bit-exact indices); list1 sharded over %d GPU(s)" % (n, n, world),
             "n_gpus": world, "scaling": "strong",
             "ms": ms, "matched_descriptors_per_s": n / (ms * 1e-3),
@@ -325,9 +326,10 @@ def main():
                          "peak": MFMA_BF16_TFLOPS,
                          "unit": "TFLOP/s per GPU",
                          "frac": mfma_flops / (ms * 1e-3) / 1e12 / MFMA_BF16_TFLOPS / world,
-                         "dtype": "bf16 (3 products per fp32 product)",
+                         "dtype": "bf16 (one MFMA product per fp32 product)",
                          "algorithmic_TFLOPs": flops / (ms * 1e-3) / 1e12,
-                         "note": "whole call: prep + prefilter + replay + overflow pass"},
+                         "note": "whole call: prep + prefilter + replay + overflow pass; the prefilter is "
+                                 "bound by its per-element VALU epilogue (4 instructions per pair), not by MFMA"},
         }
     if extra and rank == 0:
         out["extra"] = extra

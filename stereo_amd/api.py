@@ -30,7 +30,7 @@ FAST_THRESHOLD = 30  # stereo/Features.h:13
 MATCH_FAILED, MATCH_SCORE, MATCH_RATIO, MATCH_ACCEPTED = 0, 1, 2, 3
 COST_SAD, COST_SSD = 0, 1
 RECT_PRESERVE_DST, RECT_DST_IS_ZERO = 0, 1
-MATCH_AUTO, MATCH_EXACT, MATCH_MFMA, MATCH_MFMA_BF16 = 0, 1, 2, 3
+MATCH_AUTO, MATCH_EXACT, MATCH_MFMA, MATCH_MFMA_BF16, MATCH_MFMA_BF16X1 = 0, 1, 2, 3, 4
 DISP_AUTO, DISP_BRUTEFORCE = 0, 1
 
 

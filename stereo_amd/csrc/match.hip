@@ -218,11 +218,25 @@ __global__ __launch_bounds__(256) void match_prep_frag_kernel(const float *__res
 
 // squared norms (any summation order: covered by the error bound); padding rows get 0
 __global__ __launch_bounds__(256) void match_norm_kernel(const float *__restrict__ desc, int n, int npad,
-                                                         float *__restrict__ norm2)
+                                                         float *__restrict__ norm2, unsigned *__restrict__ max_bits)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= npad) return;
     float s = 0.f;
+    if (max_bits) {  // largest finite norm (bit pattern of a non-negative float orders as unsigned)
+        float v = 0.f;
+        if (r < n) {
+            const float4 *row = reinterpret_cast<const float4 *>(desc + (size_t)r * K);
+            for (int k = 0; k < K / 4; ++k) {
+                const float4 q = row[k];
+                v = fmaf(q.x, q.x, v); v = fmaf(q.y, q.y, v); v = fmaf(q.z, q.z, v); v = fmaf(q.w, q.w, v);
+            }
+            if (!(v <= 1e37f)) v = 0.f;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+        if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(max_bits, __float_as_uint(v));
+    }
+    if (r >= npad) return;
     if (r < n) {
         const float4 *row = reinterpret_cast<const float4 *>(desc + (size_t)r * K);
 #pragma unroll 8
@@ -574,6 +588,197 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// bf16 x 1 variant: only hi.hi.  Dropping both lo terms costs a relative error of
+// (2^-8 + 2^-18) on sum|a_k b_k| <= S/2, i.e. |d~ - D| <= 3.92e-3 S once doubled, plus the
+// fp32 accumulation and norm terms (< 3e-5 S together): MF_C_X1 = 4.5e-3 covers it with 14 %
+// to spare.  The looser bound only lengthens the candidate lists (26 instead of 13 per query
+// on the 200k x 200k benchmark set) while the matrix work drops to a third; the exact replay
+// is unchanged, so the outputs stay bit-identical.
+//   frag: [(jb*8 + s)*64 + lane] uint4 = 8 bf16, 8 KiB per 32-row block, 4 blocks per LDS tile
+// ---------------------------------------------------------------------------
+constexpr float MF_C_X1 = 4.5e-3f;
+constexpr int MF_TJ1 = 4;
+constexpr int MF_TILE_ROWS1 = MF_JB * MF_TJ1;
+
+__global__ __launch_bounds__(256) void match_prep_frag_bf16x1_kernel(const float *__restrict__ desc2, int n2,
+                                                                     int n2pad, uint4 *__restrict__ frag16)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // one (jb, s, lane)
+    const size_t total = (size_t)n2pad / MF_JB * 8 * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int s = (int)((idx >> 6) & 7);
+    const size_t jb = idx >> 9;
+    const size_t j = jb * MF_JB + (lane & 31);
+    uint4 hi = make_uint4(0, 0, 0, 0), lo;
+    if (j < (size_t)n2) {
+        const float4 *row = reinterpret_cast<const float4 *>(desc2 + j * K + 16 * s + 8 * (lane >> 5));
+        bf16_split8(row[0], row[1], hi, lo);
+    }
+    frag16[idx] = hi;
+}
+
+// Bound of the x1 kernel.  With e = C (|a|^2 + max_j |b_j|^2) + tiny >= C S_j + tiny for every
+// row, row j cannot be a record if an earlier row j' has d~_j' + e < d~_j - e.  |a|^2 is common
+// to both sides, so the test runs on z_j = |b_j|^2 - 2 a.b_j alone:  filtered iff z_j > Z + 2e
+// with Z = min z over (a subset of) the earlier rows.  Z is updated once per pair of rows
+// (v_min3), i.e. the second row of a pair is tested against a slightly stale -- larger, hence
+// still conservative -- bound.  4 VALU instructions per (row, query) element.
+struct BoundX1 {
+    float Z;        // running min of z
+    float T;        // Z + 2e
+    float s2;       // 2e for this lane's query
+    unsigned mask;  // bit (15 - r) set: row r of the current block may be a record
+};
+
+__device__ __forceinline__ void x1_test(BoundX1 &b, float z)
+{
+    // mask = 2*mask + !(z > T)   (v_cmp_ngt: true for NaN)
+    asm("v_cmp_ngt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+        : "+v"(b.mask) : "v"(z), "v"(b.T) : "vcc");
+}
+
+__device__ __forceinline__ void x1_step(const f32x16 &p0, const f32x16 &p1, int s, const float (&nbv)[16],
+                                        BoundX1 &b0, BoundX1 &b1)
+{
+    const int r = 2 * s;
+    const float za0 = fmaf(-2.0f, p0[r], nbv[r]), zb0 = fmaf(-2.0f, p0[r + 1], nbv[r + 1]);
+    const float za1 = fmaf(-2.0f, p1[r], nbv[r]), zb1 = fmaf(-2.0f, p1[r + 1], nbv[r + 1]);
+    x1_test(b0, za0);
+    x1_test(b0, zb0);
+    x1_test(b1, za1);
+    x1_test(b1, zb1);
+    asm("v_min3_f32 %0, %0, %1, %2" : "+v"(b0.Z) : "v"(za0), "v"(zb0));
+    asm("v_min3_f32 %0, %0, %1, %2" : "+v"(b1.Z) : "v"(za1), "v"(zb1));
+    b0.T = b0.Z + b0.s2;
+    b1.T = b1.Z + b1.s2;
+}
+
+// one 32-row block: 16 MFMAs into (n0, n1); if EPI, the epilogue of the previous block
+// (accumulators p0, p1) is sliced between the k-steps
+template <bool EPI>
+__device__ __forceinline__ void mfma_block_x1(const uint4 *bf, const bf16x8 (&qh0)[8], const bf16x8 (&qh1)[8],
+                                              f32x16 &n0, f32x16 &n1, const f32x16 &p0, const f32x16 &p1,
+                                              const float (&nbv)[16], BoundX1 &b0, BoundX1 &b1)
+{
+    f32x16 a0 = {0}, a1 = {0};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bf[s * 64]);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, qh0[s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, qh1[s], a1, 0, 0, 0);
+        if (EPI) x1_step(p0, p1, s, nbv, b0, b1);
+    }
+    n0 = a0;
+    n1 = a1;
+}
+
+__global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
+    const float *__restrict__ desc1, const float *__restrict__ qnorm, int n1,
+    const uint4 *__restrict__ frag16, const float *__restrict__ bnorm, const float *__restrict__ bmax, int n2,
+    int tiles_total, int tiles_per_seg, int *__restrict__ cand_count, int *__restrict__ cand)
+{
+    __shared__ uint4 tile[2][MF_TJ1 * 512];  // 2 x 32 KiB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const int q0i = blockIdx.x * MF_QB + wave * MF_QW + col;
+    const int q1i = q0i + 32;
+    const bool live0 = q0i < n1, live1 = q1i < n1;
+
+    bf16x8 qh0[8], qh1[8];
+    {
+        const float4 *r0 = reinterpret_cast<const float4 *>(desc1 + (size_t)(live0 ? q0i : 0) * K + 8 * half);
+        const float4 *r1 = reinterpret_cast<const float4 *>(desc1 + (size_t)(live1 ? q1i : 0) * K + 8 * half);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            uint4 h, l;
+            bf16_split8(r0[4 * s], r0[4 * s + 1], h, l);
+            if (!live0) h = make_uint4(0, 0, 0, 0);
+            qh0[s] = __builtin_bit_cast(bf16x8, h);
+            bf16_split8(r1[4 * s], r1[4 * s + 1], h, l);
+            if (!live1) h = make_uint4(0, 0, 0, 0);
+            qh1[s] = __builtin_bit_cast(bf16x8, h);
+        }
+    }
+    // 2e = 2 (C (|a|^2 + max |b|^2) + tiny); a non-finite query norm (NaN) makes T NaN: every
+    // row is emitted and the query goes to the exact kernel
+    const float nbmax = *bmax;
+    const float na0 = live0 ? qnorm[q0i] : 0.f;
+    const float na1 = live1 ? qnorm[q1i] : 0.f;
+    BoundX1 b0, b1;
+    b0.s2 = 2.0f * (MF_C_X1 * (na0 + nbmax) + MF_TINY); b0.Z = __builtin_inff(); b0.T = __builtin_inff(); b0.mask = 0;
+    b1.s2 = 2.0f * (MF_C_X1 * (na1 + nbmax) + MF_TINY); b1.Z = __builtin_inff(); b1.T = __builtin_inff(); b1.mask = 0;
+
+    const int t_begin = blockIdx.y * tiles_per_seg;
+    const int t_end = min(t_begin + tiles_per_seg, tiles_total);
+    if (t_begin >= t_end) return;
+
+    auto stage = [&](int t, int buf) {
+        const uint4 *src = frag16 + (size_t)t * MF_TJ1 * 512;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int chunk = (k * MF_WAVES + wave) * 64;  // uint4 units, 1 KiB per wave-instruction
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + chunk + lane),
+                (__attribute__((address_space(3))) void *)(&tile[buf][chunk]), 16, 0, 0);
+        }
+    };
+    auto finish = [&](int j0) {
+        b0.Z = fminf(b0.Z, __shfl_xor(b0.Z, 32));
+        b1.Z = fminf(b1.Z, __shfl_xor(b1.Z, 32));
+        b0.T = b0.Z + b0.s2;
+        b1.T = b1.Z + b1.s2;
+        const unsigned k0 = live0 ? b0.mask : 0u, k1 = live1 ? b1.mask : 0u;
+        if (__any((k0 | k1) != 0u)) {
+            emit_flagged(k0, q0i, j0, half, n2, cand_count, cand);
+            emit_flagged(k1, q1i, j0, half, n2, cand_count, cand);
+        }
+        b0.mask = 0;
+        b1.mask = 0;
+    };
+
+    stage(t_begin, 0);
+    __syncthreads();
+
+    f32x16 x0, x1, y0, y1;
+    float nbv[16];
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        if (t + 1 < t_end) stage(t + 1, buf ^ 1);
+        const uint4 *bf = tile[buf] + lane;
+        const int j0 = t * MF_TILE_ROWS1;
+        if (t == t_begin) {
+            mfma_block_x1<false>(bf, qh0, qh1, x0, x1, y0, y1, nbv, b0, b1);
+        } else {
+            load_bnorm(bnorm, j0 - MF_JB, half, nbv);
+            mfma_block_x1<true>(bf, qh0, qh1, x0, x1, y0, y1, nbv, b0, b1);
+            finish(j0 - MF_JB);
+        }
+        load_bnorm(bnorm, j0, half, nbv);
+        mfma_block_x1<true>(bf + 512, qh0, qh1, y0, y1, x0, x1, nbv, b0, b1);
+        finish(j0);
+        load_bnorm(bnorm, j0 + MF_JB, half, nbv);
+        mfma_block_x1<true>(bf + 1024, qh0, qh1, x0, x1, y0, y1, nbv, b0, b1);
+        finish(j0 + MF_JB);
+        load_bnorm(bnorm, j0 + 2 * MF_JB, half, nbv);
+        mfma_block_x1<true>(bf + 1536, qh0, qh1, y0, y1, x0, x1, nbv, b0, b1);
+        finish(j0 + 2 * MF_JB);
+        __syncthreads();
+    }
+    {   // drain: epilogue of the last block
+        const int j0 = (t_end - 1) * MF_TILE_ROWS1 + 3 * MF_JB;
+        load_bnorm(bnorm, j0, half, nbv);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) x1_step(y0, y1, s, nbv, b0, b1);
+        finish(j0);
+    }
+}
+
 // Phase 2: one wave per query.
 __global__ __launch_bounds__(64) void match_replay_kernel(
     const float *__restrict__ desc1, const float *__restrict__ score1, int n1,
@@ -669,14 +874,16 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     if (n1 <= 0) return STX_OK;
     int algo = ctx->match_algo;
     if (algo == STX_MATCH_AUTO)
-        algo = ((double)n1 * (double)n2 >= 4.0e6 && n2 >= 1024) ? STX_MATCH_MFMA_BF16 : STX_MATCH_EXACT;
+        algo = ((double)n1 * (double)n2 >= 4.0e6 && n2 >= 1024) ? STX_MATCH_MFMA_BF16X1 : STX_MATCH_EXACT;
     if (algo == STX_MATCH_EXACT || n2 == 0)
         return launch_exact(ctx, d_desc1, d_score1, n1, d_desc2, d_score2, n2, dist_limit, nullptr,
                             nullptr, d_closest, d_second, d_min_dist, d_second_dist, d_status);
 
     // ---- MFMA prefilter + replay ------------------------------------------
-    const int n2pad = (n2 + MF_TILE_ROWS - 1) / MF_TILE_ROWS * MF_TILE_ROWS;
-    const int tiles_total = n2pad / MF_TILE_ROWS;
+    const bool x1 = algo == STX_MATCH_MFMA_BF16X1;
+    const int tile_rows = x1 ? MF_TILE_ROWS1 : MF_TILE_ROWS;
+    const int n2pad = (n2 + tile_rows - 1) / tile_rows * tile_rows;
+    const int tiles_total = n2pad / tile_rows;
     const int qblocks = (n1 + MF_QB - 1) / MF_QB;
     // segments of list2: fill the CUs evenly (2 workgroups per CU), keep segments long
     const int slots = 2 * (ctx->num_cus > 0 ? ctx->num_cus : 256);
@@ -692,7 +899,7 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     segs = (tiles_total + tiles_per_seg - 1) / tiles_per_seg;
 
     int err;
-    float *frag = (float *)stx_workspace(ctx, STX_SLOT_M_FRAG, sizeof(float) * ((size_t)n2pad * K + n2pad), &err);
+    float *frag = (float *)stx_workspace(ctx, STX_SLOT_M_FRAG, sizeof(float) * ((size_t)n2pad * K + n2pad + 4), &err);
     if (!frag) return err;
     float *bnorm = frag + (size_t)n2pad * K;
     float *qnorm = (float *)stx_workspace(ctx, STX_SLOT_M_QNORM, sizeof(float) * (size_t)n1, &err);
@@ -707,15 +914,26 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     hipStream_t st = ctx->stream;
     STX_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (n1a + 4), st));
     const bool bf16 = algo == STX_MATCH_MFMA_BF16;
-    if (bf16)
+    if (x1)
+        hipLaunchKernelGGL(match_prep_frag_bf16x1_kernel, dim3((unsigned)(((size_t)n2pad / MF_JB * 512 + 255) / 256)),
+                           dim3(256), 0, st, d_desc2, n2, n2pad, reinterpret_cast<uint4 *>(frag));
+    else if (bf16)
         hipLaunchKernelGGL(match_prep_frag_bf16_kernel, dim3((unsigned)(((size_t)n2pad / MF_JB * 512 + 255) / 256)),
                            dim3(256), 0, st, d_desc2, n2, n2pad, reinterpret_cast<uint4 *>(frag));
     else
         hipLaunchKernelGGL(match_prep_frag_kernel, dim3((unsigned)(((size_t)n2pad * K / 4 + 255) / 256)), dim3(256),
                            0, st, d_desc2, n2, n2pad, frag);
-    hipLaunchKernelGGL(match_norm_kernel, dim3((n2pad + 255) / 256), dim3(256), 0, st, d_desc2, n2, n2pad, bnorm);
-    hipLaunchKernelGGL(match_norm_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_desc1, n1, n1, qnorm);
-    if (bf16)
+    unsigned *bmax = reinterpret_cast<unsigned *>(bnorm + n2pad);
+    if (x1) STX_HIP(hipMemsetAsync(bmax, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(match_norm_kernel, dim3((n2pad + 255) / 256), dim3(256), 0, st, d_desc2, n2, n2pad, bnorm,
+                       x1 ? bmax : (unsigned *)nullptr);
+    hipLaunchKernelGGL(match_norm_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_desc1, n1, n1, qnorm,
+                       (unsigned *)nullptr);
+    if (x1)
+        hipLaunchKernelGGL(match_mfma_bf16x1_kernel, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm,
+                           n1, reinterpret_cast<const uint4 *>(frag), bnorm, reinterpret_cast<const float *>(bmax), n2,
+                           tiles_total, tiles_per_seg, cnt, cand);
+    else if (bf16)
         hipLaunchKernelGGL(match_mfma_bf16_kernel, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm,
                            n1, reinterpret_cast<const uint4 *>(frag), bnorm, n2, tiles_total, tiles_per_seg, cnt,
                            cand);

@@ -446,7 +446,7 @@ def _match_equal(got, want):
             assert g.tobytes() == w.tobytes(), "%s differs at %s" % (n, np.nonzero(g != w)[0][:8])
 
 
-ALGOS = [api.MATCH_EXACT, api.MATCH_MFMA, api.MATCH_MFMA_BF16, api.MATCH_AUTO]
+ALGOS = [api.MATCH_EXACT, api.MATCH_MFMA, api.MATCH_MFMA_BF16, api.MATCH_MFMA_BF16X1, api.MATCH_AUTO]
 
 
 @pytest.mark.parametrize("algo", ALGOS)
