@@ -639,36 +639,49 @@ __device__ __forceinline__ void x1_test(BoundX1 &b, float z)
         : "+v"(b.mask) : "v"(z), "v"(b.T) : "vcc");
 }
 
+// epilogue slice for one column block and k-step s: accumulator registers 2s and 2s+1
+__device__ __forceinline__ void x1_half(const f32x16 &p, int s, const float (&nbv)[16], BoundX1 &b)
+{
+    const int r = 2 * s;
+    const float za = fmaf(-2.0f, p[r], nbv[r]), zb = fmaf(-2.0f, p[r + 1], nbv[r + 1]);
+    x1_test(b, za);
+    x1_test(b, zb);
+    asm("v_min3_f32 %0, %0, %1, %2" : "+v"(b.Z) : "v"(za), "v"(zb));
+    b.T = b.Z + b.s2;
+}
+
 __device__ __forceinline__ void x1_step(const f32x16 &p0, const f32x16 &p1, int s, const float (&nbv)[16],
                                         BoundX1 &b0, BoundX1 &b1)
 {
-    const int r = 2 * s;
-    const float za0 = fmaf(-2.0f, p0[r], nbv[r]), zb0 = fmaf(-2.0f, p0[r + 1], nbv[r + 1]);
-    const float za1 = fmaf(-2.0f, p1[r], nbv[r]), zb1 = fmaf(-2.0f, p1[r + 1], nbv[r + 1]);
-    x1_test(b0, za0);
-    x1_test(b0, zb0);
-    x1_test(b1, za1);
-    x1_test(b1, zb1);
-    asm("v_min3_f32 %0, %0, %1, %2" : "+v"(b0.Z) : "v"(za0), "v"(zb0));
-    asm("v_min3_f32 %0, %0, %1, %2" : "+v"(b1.Z) : "v"(za1), "v"(zb1));
-    b0.T = b0.Z + b0.s2;
-    b1.T = b1.Z + b1.s2;
+    x1_half(p0, s, nbv, b0);
+    x1_half(p1, s, nbv, b1);
 }
 
 // one 32-row block: 16 MFMAs into (n0, n1); if EPI, the epilogue of the previous block
-// (accumulators p0, p1) is sliced between the k-steps
+// (accumulators p0, p1) is sliced between the MFMAs.  A wave issues in order, so the
+// interleave is pinned with scheduling barriers: MFMA, 8 VALU, MFMA, 8 VALU per k-step (left
+// alone the compiler bunches the MFMAs at the top of the block and the VALU work then runs
+// with the matrix pipe idle).  The A fragment of the next k-step is read one step ahead.
 template <bool EPI>
 __device__ __forceinline__ void mfma_block_x1(const uint4 *bf, const bf16x8 (&qh0)[8], const bf16x8 (&qh1)[8],
                                               f32x16 &n0, f32x16 &n1, const f32x16 &p0, const f32x16 &p1,
                                               const float (&nbv)[16], BoundX1 &b0, BoundX1 &b1)
 {
     f32x16 a0 = {0}, a1 = {0};
+    uint4 cur = bf[0];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, bf[s * 64]);
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, cur);
+        if (s < 7) cur = bf[(s + 1) * 64];
+        __builtin_amdgcn_sched_barrier(0);
         a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, qh0[s], a0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (EPI) x1_half(p0, s, nbv, b0);
+        __builtin_amdgcn_sched_barrier(0);
         a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, qh1[s], a1, 0, 0, 0);
-        if (EPI) x1_step(p0, p1, s, nbv, b0, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (EPI) x1_half(p1, s, nbv, b1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     n0 = a0;
     n1 = a1;
@@ -745,36 +758,38 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
     stage(t_begin, 0);
     __syncthreads();
 
+    // The norms of a block are loaded one block ahead of the epilogue that uses them (two
+    // register sets, nA / nB): a load issued right before its use stalls both waves of the SIMD
+    // for an L2 round trip per block, which was half of this kernel's time.
     f32x16 x0, x1, y0, y1;
-    float nbv[16];
+    float nA[16], nB[16];
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
         if (t + 1 < t_end) stage(t + 1, buf ^ 1);
         const uint4 *bf = tile[buf] + lane;
         const int j0 = t * MF_TILE_ROWS1;
+        load_bnorm(bnorm, j0, half, nA);
         if (t == t_begin) {
-            mfma_block_x1<false>(bf, qh0, qh1, x0, x1, y0, y1, nbv, b0, b1);
+            mfma_block_x1<false>(bf, qh0, qh1, x0, x1, y0, y1, nB, b0, b1);
         } else {
-            load_bnorm(bnorm, j0 - MF_JB, half, nbv);
-            mfma_block_x1<true>(bf, qh0, qh1, x0, x1, y0, y1, nbv, b0, b1);
+            mfma_block_x1<true>(bf, qh0, qh1, x0, x1, y0, y1, nB, b0, b1);
             finish(j0 - MF_JB);
         }
-        load_bnorm(bnorm, j0, half, nbv);
-        mfma_block_x1<true>(bf + 512, qh0, qh1, y0, y1, x0, x1, nbv, b0, b1);
+        load_bnorm(bnorm, j0 + MF_JB, half, nB);
+        mfma_block_x1<true>(bf + 512, qh0, qh1, y0, y1, x0, x1, nA, b0, b1);
         finish(j0);
-        load_bnorm(bnorm, j0 + MF_JB, half, nbv);
-        mfma_block_x1<true>(bf + 1024, qh0, qh1, x0, x1, y0, y1, nbv, b0, b1);
+        load_bnorm(bnorm, j0 + 2 * MF_JB, half, nA);
+        mfma_block_x1<true>(bf + 1024, qh0, qh1, x0, x1, y0, y1, nB, b0, b1);
         finish(j0 + MF_JB);
-        load_bnorm(bnorm, j0 + 2 * MF_JB, half, nbv);
-        mfma_block_x1<true>(bf + 1536, qh0, qh1, y0, y1, x0, x1, nbv, b0, b1);
+        load_bnorm(bnorm, j0 + 3 * MF_JB, half, nB);
+        mfma_block_x1<true>(bf + 1536, qh0, qh1, y0, y1, x0, x1, nA, b0, b1);
         finish(j0 + 2 * MF_JB);
         __syncthreads();
     }
     {   // drain: epilogue of the last block
         const int j0 = (t_end - 1) * MF_TILE_ROWS1 + 3 * MF_JB;
-        load_bnorm(bnorm, j0, half, nbv);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) x1_step(y0, y1, s, nbv, b0, b1);
+        for (int s = 0; s < 8; ++s) x1_step(y0, y1, s, nB, b0, b1);
         finish(j0);
     }
 }
