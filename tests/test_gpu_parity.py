@@ -342,6 +342,62 @@ def test_rectify_singular_and_different_sizes(ctx, oracle):
     assert (ctx.rectify(src, np.full((33, 61), 9, np.uint8), Hinv) == want).all()
 
 
+def test_rectify_divide_ranges(ctx, oracle):
+    """The kernel divides with a shared reciprocal when |q0|, |q1|, |q2| lie in [2^-40, 2^40]
+    and with the full IEEE divide otherwise; both must give the oracle's x86 quotients bit for
+    bit.  A homography scaled by 2^k maps every pixel to the same source coordinate, so the
+    scaled inverses walk the guard's limits, the v_div_scale ranges and the denormals."""
+    h, w = 37, 211
+    src = synth.texture(9, h, w)
+    base = oracle.invert3x3(synth.homography(9, w, h, deg_y=1.5)).astype(np.float32)
+    want0 = oracle.rectify(src, np.full((h, w), 5, np.uint8), base)
+    assert (want0 != 5).sum() > h * w // 2
+    for k in [-149, -140, -126, -110, -100, -64, -41, -40, -39, -30, 0, 30, 28, 39, 40, 41, 64, 100, 110, 120]:
+        Hinv = (base * np.float32(2.0) ** np.float32(k)).astype(np.float32) if k > -127 else \
+            (base * np.float32(2.0 ** -100) * np.float32(2.0 ** (k + 100))).astype(np.float32)
+        want = oracle.rectify(src, np.full((h, w), 5, np.uint8), Hinv)
+        got = ctx.rectify(src, np.full((h, w), 5, np.uint8), Hinv)
+        assert (got == want).all(), "scale 2^%d: %d pixels differ" % (k, (got != want).sum())
+        if -60 <= k <= 60:
+            assert (want == want0).all()
+    # coordinates that cross zero inside the image (exact 0 and tiny numerators), a zero third
+    # row (division by zero), infinities and NaNs
+    cases = [
+        [[1, 0, -100.25], [0, 1, -10.5], [0, 0, 1]],
+        [[1, 0, 0.5], [0, 1, -17.25], [0, 0, 1]],
+        [[1, 1e-30, 0.25], [1e-30, 1, 0.75], [0, 0, 1]],
+        [[1, 0, 0.5], [0, 1, 0.5], [0, 0, 0]],
+        [[1, 0, 0.5], [0, 1, 0.5], [1e-3, 0, -0.1]],
+        [[1, 0, 0.5], [0, 1, 0.5], [0, 0, np.inf]],
+        [[np.nan, 0, 0.5], [0, 1, 0.5], [0, 0, 1]],
+        [[1, 0, 0.5], [0, np.inf, 0.5], [0, 0, 1]],
+        [[1e-42, 0, 1e-41], [0, 1e-42, 1e-41], [0, 0, 1e-42]],
+        [[3e38, 0, 3e38], [0, 3e38, 3e38], [0, 0, 3e38]],
+        [[1, 0, 0.5], [0, 1, 0.5], [0, 0, 3e38]],
+        [[1e-20, 0, 1e-20], [0, 1e-20, 1e-20], [0, 0, 1e20]],
+        [[1e20, 0, 1e20], [0, 1e20, 1e20], [0, 0, 1e-19]],
+    ]
+    for c in cases:
+        Hinv = np.array(c, np.float32)
+        with np.errstate(all="ignore"):
+            want = oracle.rectify(src, np.full((h, w), 5, np.uint8), Hinv)
+            got = ctx.rectify(src, np.full((h, w), 5, np.uint8), Hinv)
+            got0 = ctx.rectify(src, np.zeros((h, w), np.uint8), Hinv, api.RECT_DST_IS_ZERO)
+            want0z = oracle.rectify(src, np.zeros((h, w), np.uint8), Hinv)
+        assert (got == want).all(), "case %s: %d pixels differ" % (c, (got != want).sum())
+        assert (got0 == want0z).all()
+
+
+def test_rectify_tiny_sources(ctx, oracle):
+    """Sources smaller than 2x2 have no in-bounds coordinate: nothing may be read or written."""
+    for sh, sw in [(1, 1), (1, 40), (40, 1), (2, 2), (2, 9), (3, 3)]:
+        src = synth.texture(sh * 7 + sw, sh, sw)
+        Hinv = np.array([[0.01, 0, 0.3], [0, 0.01, 0.4], [0, 0, 1]], np.float32)
+        want = oracle.rectify(src, np.full((20, 70), 3, np.uint8), Hinv)
+        got = ctx.rectify(src, np.full((20, 70), 3, np.uint8), Hinv)
+        assert (got == want).all()
+
+
 def test_rectify_pitched_and_golden(ctx, oracle):
     g = np.load(os.path.join(GOLD, "r_64x48.npz"))
     got = ctx.rectify(g["src"], g["dst0"].copy(), g["Hinv"])
