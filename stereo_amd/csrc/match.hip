@@ -148,7 +148,8 @@ constexpr int MF_JB = 32;              // list2 rows per MFMA row block
 constexpr int MF_TJ = 2;               // row blocks per LDS tile
 constexpr int MF_TILE_ROWS = MF_JB * MF_TJ;
 constexpr int MF_BLOCK_FLOATS = MF_JB * K;  // 4096 floats = 16 KiB per row block
-constexpr int MF_CAP = 256;            // candidate slots per query
+constexpr int MF_CAP = 256;            // candidates per query that the replay kernel sorts
+constexpr int MF_SLOTS_X1 = 512;       // x1 kernel: slots per query, shared by its private sub-lists
 constexpr float MF_C = 6.103515625e-05f;  // 2^-14 >= 523 * 2^-24
 constexpr float MF_TINY = 1e-37f;      // covers underflow in either computation
 
@@ -596,13 +597,41 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16_kernel(
 // on the 200k x 200k benchmark set) while the matrix work drops to a third; the exact replay
 // is unchanged, so the outputs stay bit-identical.
 //   frag: [(jb*8 + s)*64 + lane] uint4 = 8 bf16, 8 KiB per 32-row block, 4 blocks per LDS tile
+//
+// The whole bound lives in the accumulator.  With h_j = |b_j|^2 / 2 the MFMA chain of a block
+// starts from C = -h_j instead of 0, so it ends in y_j = a.b_j - h_j = -(|b_j|^2 - 2 a.b_j)/2:
+// larger y = closer row, and |a|^2 is common to all rows of a query.  With
+// e = C (|a|^2 + max_j |b_j|^2) + tiny, row j cannot be a record if an earlier row j' has
+// d~_j' + e_j' < d~_j - e_j, which holds whenever y_j < Y - e, Y = max of y over (a subset
+// of) the earlier rows.  Records are rare (tens per query in 200 000 rows), so the test runs
+// per BLOCK: one v_max3_f32 per two rows folds the block's 16 y values of a lane into M, and
+// only if some lane of the wave has !(M < Y - e) does the wave run the per-row tests of that
+// block (same accumulators, still live).  Half a VALU instruction per (row, query) element
+// instead of four: the kernel is bound by the matrix pipe.
+//
+// v_max3_f32 drops NaNs, so nothing that must be emitted may hide behind one: a row whose
+// norm is not finite (or above 1e37) gets h = -inf and a zeroed fragment, hence y = +inf --
+// always a candidate, and excluded from Y in the per-row pass; a query with a non-finite norm
+// has e = NaN, every comparison fails and every block takes the per-row pass, which emits
+// all rows (the query overflows to the exact kernel).
 // ---------------------------------------------------------------------------
 constexpr float MF_C_X1 = 4.5e-3f;
 constexpr int MF_TJ1 = 4;
 constexpr int MF_TILE_ROWS1 = MF_JB * MF_TJ1;
 
+// -|b_j|^2 / 2 per row of list2 (padding rows 0, unbounded rows +inf = "-h" with h = -inf)
+__global__ __launch_bounds__(256) void match_neg_half_norm_kernel(const float *__restrict__ bnorm, int npad,
+                                                                   float *__restrict__ nh)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= npad) return;
+    const float s = bnorm[r];
+    nh[r] = s == s ? -0.5f * s : __builtin_inff();
+}
+
 __global__ __launch_bounds__(256) void match_prep_frag_bf16x1_kernel(const float *__restrict__ desc2, int n2,
-                                                                     int n2pad, uint4 *__restrict__ frag16)
+                                                                     int n2pad, const float *__restrict__ bnorm,
+                                                                     uint4 *__restrict__ frag16)
 {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // one (jb, s, lane)
     const size_t total = (size_t)n2pad / MF_JB * 8 * 64;
@@ -612,85 +641,159 @@ __global__ __launch_bounds__(256) void match_prep_frag_bf16x1_kernel(const float
     const size_t jb = idx >> 9;
     const size_t j = jb * MF_JB + (lane & 31);
     uint4 hi = make_uint4(0, 0, 0, 0), lo;
-    if (j < (size_t)n2) {
+    if (j < (size_t)n2 && bnorm[j] == bnorm[j]) {  // unbounded rows (NaN norm) enter as zeros
         const float4 *row = reinterpret_cast<const float4 *>(desc2 + j * K + 16 * s + 8 * (lane >> 5));
         bf16_split8(row[0], row[1], hi, lo);
     }
     frag16[idx] = hi;
 }
 
-// Bound of the x1 kernel.  With e = C (|a|^2 + max_j |b_j|^2) + tiny >= C S_j + tiny for every
-// row, row j cannot be a record if an earlier row j' has d~_j' + e < d~_j - e.  |a|^2 is common
-// to both sides, so the test runs on z_j = |b_j|^2 - 2 a.b_j alone:  filtered iff z_j > Z + 2e
-// with Z = min z over (a subset of) the earlier rows.  Z is updated once per pair of rows
-// (v_min3), i.e. the second row of a pair is tested against a slightly stale -- larger, hence
-// still conservative -- bound.  4 VALU instructions per (row, query) element.
 struct BoundX1 {
-    float Z;        // running min of z
-    float T;        // Z + 2e
-    float s2;       // 2e for this lane's query
+    float Y;        // running max of y over the rows seen so far
+    float T;        // Y - e: rows with y < T cannot be records
+    float e;        // C (|a|^2 + max |b|^2) + tiny for this lane's query
+    float M;        // max of y over the block being closed
     unsigned mask;  // bit (15 - r) set: row r of the current block may be a record
+    int cnt;        // rows appended to this lane's private candidate list so far
 };
 
-__device__ __forceinline__ void x1_test(BoundX1 &b, float z)
+// Candidate lists of the x1 kernel.  A lane owns one (query, segment of list2, half of the
+// 32-row blocks) and appends to a private sub-list of that query: nsub = 2 * segments
+// sub-lists of subcap slots each.  No atomics, so nothing in the MFMA loop ever waits for a
+// memory round trip; the count is kept in a register and stored once at the end.
+__device__ __forceinline__ void x1_emit(unsigned mask, int &cnt, int *__restrict__ list, int subcap, int j0,
+                                        int half, int n2)
 {
-    // mask = 2*mask + !(z > T)   (v_cmp_ngt: true for NaN)
-    asm("v_cmp_ngt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-        : "+v"(b.mask) : "v"(z), "v"(b.T) : "vcc");
-}
-
-// epilogue slice for one column block and k-step s: accumulator registers 2s and 2s+1
-__device__ __forceinline__ void x1_half(const f32x16 &p, int s, const float (&nbv)[16], BoundX1 &b)
-{
-    const int r = 2 * s;
-    const float za = fmaf(-2.0f, p[r], nbv[r]), zb = fmaf(-2.0f, p[r + 1], nbv[r + 1]);
-    x1_test(b, za);
-    x1_test(b, zb);
-    asm("v_min3_f32 %0, %0, %1, %2" : "+v"(b.Z) : "v"(za), "v"(zb));
-    b.T = b.Z + b.s2;
-}
-
-__device__ __forceinline__ void x1_step(const f32x16 &p0, const f32x16 &p1, int s, const float (&nbv)[16],
-                                        BoundX1 &b0, BoundX1 &b1)
-{
-    x1_half(p0, s, nbv, b0);
-    x1_half(p1, s, nbv, b1);
-}
-
-// one 32-row block: 16 MFMAs into (n0, n1); if EPI, the epilogue of the previous block
-// (accumulators p0, p1) is sliced between the MFMAs.  A wave issues in order, so the
-// interleave is pinned with scheduling barriers: MFMA, 8 VALU, MFMA, 8 VALU per k-step (left
-// alone the compiler bunches the MFMAs at the top of the block and the VALU work then runs
-// with the matrix pipe idle).  The A fragment of the next k-step is read one step ahead.
-template <bool EPI>
-__device__ __forceinline__ void mfma_block_x1(const uint4 *bf, const bf16x8 (&qh0)[8], const bf16x8 (&qh1)[8],
-                                              f32x16 &n0, f32x16 &n1, const f32x16 &p0, const f32x16 &p1,
-                                              const float (&nbv)[16], BoundX1 &b0, BoundX1 &b1)
-{
-    f32x16 a0 = {0}, a1 = {0};
-    uint4 cur = bf[0];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, cur);
-        if (s < 7) cur = bf[(s + 1) * 64];
-        __builtin_amdgcn_sched_barrier(0);
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, qh0[s], a0, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (EPI) x1_half(p0, s, nbv, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, qh1[s], a1, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (EPI) x1_half(p1, s, nbv, b1);
-        __builtin_amdgcn_sched_barrier(0);
+    while (mask) {
+        const int bit = 31 - __clz((int)mask);
+        mask &= ~(1u << bit);
+        const int r = 15 - bit;
+        const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (j < n2) {
+            if (cnt < subcap) list[cnt] = j;
+            ++cnt;
+        }
     }
-    n0 = a0;
-    n1 = a1;
 }
 
+__device__ __forceinline__ void x1_test(BoundX1 &b, float y)
+{
+    // mask = 2*mask + !(y < T)   (v_cmp_nlt: true for NaN)
+    asm("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+        : "+v"(b.mask) : "v"(y), "v"(b.T) : "vcc");
+}
+
+// per-row pass over one block (rare): the bound is refreshed after every pair of rows, i.e.
+// the second row of a pair is tested against a slightly stale -- lower, hence still
+// conservative -- bound.  y = +inf marks an unbounded row: emitted, never part of Y
+// (SPECIAL: some lane of the wave has such a row in this block).
+template <bool SPECIAL>
+__device__ __forceinline__ void x1_rows(const f32x16 &p, BoundX1 &b)
+{
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const float ya = p[r], yb = p[r + 1];
+        x1_test(b, ya);
+        x1_test(b, yb);
+        if (SPECIAL) {
+            const float fa = ya < __builtin_inff() ? ya : -__builtin_inff();
+            const float fb = yb < __builtin_inff() ? yb : -__builtin_inff();
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(b.Y) : "v"(fa), "v"(fb));
+        } else {
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(b.Y) : "v"(ya), "v"(yb));
+        }
+        b.T = b.Y - b.e;
+    }
+}
+
+// rows of this lane in a 32-row block, in accumulator-register order r = 0..15:
+//   j = j0 + (r&3) + 8*(r>>2) + 4*half
+__device__ __forceinline__ f32x16 load_nh(const float *__restrict__ nh, int j0, int half)
+{
+    const float4 *p = reinterpret_cast<const float4 *>(nh + j0 + 4 * half);
+    f32x16 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 t = p[2 * q];
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+    return v;
+}
+
+// the 8 A fragments (k-steps) of one 32-row block: 8 conflict-free ds_read_b128
+__device__ __forceinline__ void load_frag(const uint4 *bf, uint4 (&f)[8])
+{
+#pragma unroll
+    for (int s = 0; s < 8; ++s) f[s] = bf[s * 64];
+}
+
+// Close one 32-query chain of the block whose y values are still in acc: fold them into
+// b.M; if some lane of the wave may hold a record, run the per-row pass and append the
+// flagged rows.  Afterwards acc may be overwritten.
+template <int DBG>
+__device__ __forceinline__ void x1_close(const f32x16 &acc, BoundX1 &b, bool live, int j0, int half,
+                                         int n2, int *__restrict__ list, int subcap)
+{
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(b.M) : "v"(acc[r]), "v"(acc[r + 1]));
+    if (DBG == 2) return;
+    const bool hit = !(b.M < b.T);
+    if (DBG != 1 && __any(hit)) {
+        if (__any(b.M == __builtin_inff()))
+            x1_rows<true>(acc, b);
+        else
+            x1_rows<false>(acc, b);
+        const unsigned k = live ? b.mask : 0u;
+        if (__any(k != 0u)) x1_emit(k, b.cnt, list, subcap, j0, half, n2);
+        b.mask = 0;
+        b.M = -__builtin_inff();
+    }
+}
+
+// after both chains of a block are closed: Y takes the block maximum, the two half-waves (which
+// hold the two halves of each query's rows) exchange it, and the threshold follows
+__device__ __forceinline__ void x1_update(BoundX1 &b)
+{
+    float y;
+    asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(b.Y), "v"(b.M));
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+    asm("v_max_f32 %0, %1, %2" : "=v"(b.Y) : "v"(__uint_as_float(sw[0])), "v"(__uint_as_float(sw[1])));
+    b.T = b.Y - b.e;
+    b.M = -__builtin_inff();
+}
+
+// One 32-row block: 16 MFMAs into (a0, a1), both chains starting from c = -h.  Unless FIRST,
+// (a0, a1) still hold the previous block (rows from jprev): each chain is closed right before
+// its first MFMA overwrites it, so the matrix pipe only waits for eight v_max3 per chain.
+template <bool FIRST, int DBG>
+__device__ __forceinline__ void x1_block(const uint4 (&f)[8], const bf16x8 (&qh0)[8], const bf16x8 (&qh1)[8],
+                                         const f32x16 &c, f32x16 &a0, f32x16 &a1, BoundX1 &b0, BoundX1 &b1,
+                                         bool live0, bool live1, int jprev, int half, int n2,
+                                         int *__restrict__ list0, int *__restrict__ list1, int subcap)
+{
+    const bf16x8 f0 = __builtin_bit_cast(bf16x8, f[0]);
+    if (!FIRST) x1_close<DBG>(a0, b0, live0, jprev, half, n2, list0, subcap);
+    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, qh0[0], c, 0, 0, 0);
+    if (!FIRST) x1_close<DBG>(a1, b1, live1, jprev, half, n2, list1, subcap);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, qh1[0], c, 0, 0, 0);
+    if (!FIRST) {
+        x1_update(b0);
+        x1_update(b1);
+    }
+#pragma unroll
+    for (int s = 1; s < 8; ++s) {
+        const bf16x8 fs = __builtin_bit_cast(bf16x8, f[s]);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fs, qh0[s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fs, qh1[s], a1, 0, 0, 0);
+    }
+}
+
+template <int DBG>
 __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
     const float *__restrict__ desc1, const float *__restrict__ qnorm, int n1,
-    const uint4 *__restrict__ frag16, const float *__restrict__ bnorm, const float *__restrict__ bmax, int n2,
-    int tiles_total, int tiles_per_seg, int *__restrict__ cand_count, int *__restrict__ cand)
+    const uint4 *__restrict__ frag16, const float *__restrict__ nh, const float *__restrict__ bmax, int n2,
+    int tiles_total, int tiles_per_seg, int nsub, int subcap, int *__restrict__ cand_count,
+    int *__restrict__ cand)
 {
     __shared__ uint4 tile[2][MF_TJ1 * 512];  // 2 x 32 KiB
 
@@ -718,18 +821,35 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
             qh1[s] = __builtin_bit_cast(bf16x8, h);
         }
     }
-    // 2e = 2 (C (|a|^2 + max |b|^2) + tiny); a non-finite query norm (NaN) makes T NaN: every
-    // row is emitted and the query goes to the exact kernel
+    // e = C (|a|^2 + max |b|^2) + tiny in the units of d~ = |a|^2 - 2y; on y the test
+    // d~_j' + e < d~_j - e reads y_j < y_j' - e.  A non-finite query norm (NaN) makes T NaN:
+    // every row is emitted and the query goes to the exact kernel.
     const float nbmax = *bmax;
     const float na0 = live0 ? qnorm[q0i] : 0.f;
     const float na1 = live1 ? qnorm[q1i] : 0.f;
     BoundX1 b0, b1;
-    b0.s2 = 2.0f * (MF_C_X1 * (na0 + nbmax) + MF_TINY); b0.Z = __builtin_inff(); b0.T = __builtin_inff(); b0.mask = 0;
-    b1.s2 = 2.0f * (MF_C_X1 * (na1 + nbmax) + MF_TINY); b1.Z = __builtin_inff(); b1.T = __builtin_inff(); b1.mask = 0;
+    b0.e = MF_C_X1 * (na0 + nbmax) + MF_TINY;
+    b1.e = MF_C_X1 * (na1 + nbmax) + MF_TINY;
+    b0.Y = b1.Y = b0.M = b1.M = -__builtin_inff();
+    b0.T = b0.Y - b0.e;
+    b1.T = b1.Y - b1.e;
+    b0.mask = b1.mask = 0;
+    b0.cnt = b1.cnt = 0;
+    const int sub = 2 * blockIdx.y + half;  // this lane's sub-list of its two queries
+    int *count0 = cand_count + (size_t)(live0 ? q0i : 0) * nsub + sub;
+    int *count1 = cand_count + (size_t)(live1 ? q1i : 0) * nsub + sub;
+    int *list0 = cand + ((size_t)(live0 ? q0i : 0) * nsub + sub) * subcap;
+    int *list1 = cand + ((size_t)(live1 ? q1i : 0) * nsub + sub) * subcap;
 
     const int t_begin = blockIdx.y * tiles_per_seg;
     const int t_end = min(t_begin + tiles_per_seg, tiles_total);
-    if (t_begin >= t_end) return;
+    if (t_begin >= t_end) {
+        if (live0) *count0 = 0;
+        if (live1) *count1 = 0;
+        return;
+    }
+    const int ntiles = t_end - t_begin;
+    const int j_last = (tiles_total * MF_TJ1 - 1) * MF_JB;  // first row of the last block of list2
 
     auto stage = [&](int t, int buf) {
         const uint4 *src = frag16 + (size_t)t * MF_TJ1 * 512;
@@ -741,64 +861,64 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
                 (__attribute__((address_space(3))) void *)(&tile[buf][chunk]), 16, 0, 0);
         }
     };
-    auto finish = [&](int j0) {
-        b0.Z = fminf(b0.Z, __shfl_xor(b0.Z, 32));
-        b1.Z = fminf(b1.Z, __shfl_xor(b1.Z, 32));
-        b0.T = b0.Z + b0.s2;
-        b1.T = b1.Z + b1.s2;
-        const unsigned k0 = live0 ? b0.mask : 0u, k1 = live1 ? b1.mask : 0u;
-        if (__any((k0 | k1) != 0u)) {
-            emit_flagged(k0, q0i, j0, half, n2, cand_count, cand);
-            emit_flagged(k1, q1i, j0, half, n2, cand_count, cand);
-        }
-        b0.mask = 0;
-        b1.mask = 0;
-    };
 
+    // Everything a block needs -- its 8 A fragments (LDS) and its 16 seeds -h (L2) -- is
+    // loaded into registers one whole block (>= 512 matrix cycles) ahead of its MFMA chain; two
+    // register sets alternate.  LDS tiles are double buffered with one barrier per tile, placed
+    // before the tile's last block: by then every wave has its last fragments of this tile in
+    // registers, so the buffer can be refilled (tile + 2) and the next tile's first block read.
     stage(t_begin, 0);
     __syncthreads();
-
-    // The norms of a block are loaded one block ahead of the epilogue that uses them (two
-    // register sets, nA / nB): a load issued right before its use stalls both waves of the SIMD
-    // for an L2 round trip per block, which was half of this kernel's time.
-    f32x16 x0, x1, y0, y1;
-    float nA[16], nB[16];
-    for (int t = t_begin; t < t_end; ++t) {
-        const int buf = (t - t_begin) & 1;
-        if (t + 1 < t_end) stage(t + 1, buf ^ 1);
+    if (ntiles > 1) stage(t_begin + 1, 1);
+    uint4 fA[8], fB[8];
+    f32x16 cA, cB, a0, a1;
+    load_frag(tile[0] + lane, fA);
+    cA = load_nh(nh, t_begin * MF_TILE_ROWS1, half);
+#define X1_BLOCK(FIRST, F, C, JPREV)                                                                   \
+    x1_block<FIRST, DBG>(F, qh0, qh1, C, a0, a1, b0, b1, live0, live1, JPREV, half, n2, list0, list1, subcap)
+    for (int tt = 0; tt < ntiles; ++tt) {
+        const int buf = tt & 1;
         const uint4 *bf = tile[buf] + lane;
-        const int j0 = t * MF_TILE_ROWS1;
-        load_bnorm(bnorm, j0, half, nA);
-        if (t == t_begin) {
-            mfma_block_x1<false>(bf, qh0, qh1, x0, x1, y0, y1, nB, b0, b1);
-        } else {
-            mfma_block_x1<true>(bf, qh0, qh1, x0, x1, y0, y1, nB, b0, b1);
-            finish(j0 - MF_JB);
-        }
-        load_bnorm(bnorm, j0 + MF_JB, half, nB);
-        mfma_block_x1<true>(bf + 512, qh0, qh1, y0, y1, x0, x1, nA, b0, b1);
-        finish(j0);
-        load_bnorm(bnorm, j0 + 2 * MF_JB, half, nA);
-        mfma_block_x1<true>(bf + 1024, qh0, qh1, x0, x1, y0, y1, nB, b0, b1);
-        finish(j0 + MF_JB);
-        load_bnorm(bnorm, j0 + 3 * MF_JB, half, nB);
-        mfma_block_x1<true>(bf + 1536, qh0, qh1, y0, y1, x0, x1, nA, b0, b1);
-        finish(j0 + 2 * MF_JB);
-        __syncthreads();
+        const int j0 = (t_begin + tt) * MF_TILE_ROWS1;
+        load_frag(bf + 512, fB);
+        cB = load_nh(nh, j0 + MF_JB, half);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tt == 0)
+            X1_BLOCK(true, fA, cA, 0);
+        else
+            X1_BLOCK(false, fA, cA, j0 - MF_JB);
+        load_frag(bf + 1024, fA);
+        cA = load_nh(nh, j0 + 2 * MF_JB, half);
+        __builtin_amdgcn_sched_barrier(0);
+        X1_BLOCK(false, fB, cB, j0);
+        load_frag(bf + 1536, fB);
+        cB = load_nh(nh, j0 + 3 * MF_JB, half);
+        __builtin_amdgcn_sched_barrier(0);
+        X1_BLOCK(false, fA, cA, j0 + MF_JB);
+        __syncthreads();  // tile tt + 1 has landed; nobody reads tile tt from LDS any more
+        if (tt + 2 < ntiles) stage(t_begin + tt + 2, buf);
+        if (tt + 1 < ntiles) load_frag(tile[buf ^ 1] + lane, fA);
+        cA = load_nh(nh, min(j0 + 4 * MF_JB, j_last), half);
+        __builtin_amdgcn_sched_barrier(0);
+        X1_BLOCK(false, fB, cB, j0 + 2 * MF_JB);
     }
-    {   // drain: epilogue of the last block
+#undef X1_BLOCK
+    {   // drain: the last block
         const int j0 = (t_end - 1) * MF_TILE_ROWS1 + 3 * MF_JB;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) x1_step(y0, y1, s, nB, b0, b1);
-        finish(j0);
+        x1_close<DBG>(a0, b0, live0, j0, half, n2, list0, subcap);
+        x1_close<DBG>(a1, b1, live1, j0, half, n2, list1, subcap);
     }
+    if (live0) *count0 = b0.cnt;
+    if (live1) *count1 = b1.cnt;
+    if (DBG && b0.M + b1.M + b0.Y + b1.Y == 123.456f) cand[0] = 1;
 }
 
 // Phase 2: one wave per query.
 __global__ __launch_bounds__(64) void match_replay_kernel(
     const float *__restrict__ desc1, const float *__restrict__ score1, int n1,
     const float *__restrict__ desc2, const float *__restrict__ score2, int n2, float dist_limit,
-    const int *__restrict__ cand_count, const int *__restrict__ cand, int *__restrict__ overflow_count,
+    const int *__restrict__ cand_count, const int *__restrict__ cand, int nsub, int subcap,
+    int *__restrict__ overflow_count,
     int *__restrict__ overflow_list, int32_t *__restrict__ closest_out, int32_t *__restrict__ second_out,
     float *__restrict__ min_dist_out, float *__restrict__ second_dist_out, uint8_t *__restrict__ status_out)
 {
@@ -808,12 +928,25 @@ __global__ __launch_bounds__(64) void match_replay_kernel(
     __shared__ float q[K];
     const int i = blockIdx.x;
     const int lane = threadIdx.x;
-    const int count = cand_count[i];
-    if (count > MF_CAP) {  // too many near-ties: exact scan for this query
+    // the query's candidates: nsub sub-lists of at most subcap entries (one list for the atomic
+    // kernels, one per (segment, half) for the x1 kernel)
+    int count = 0;
+    bool overflow = false;
+    for (int s = 0; s < nsub; ++s) {
+        const int c = cand_count[(size_t)i * nsub + s];
+        overflow |= c > subcap;
+        count += c;
+    }
+    if (overflow || count > MF_CAP) {  // too many near-ties: exact scan for this query
         if (lane == 0) overflow_list[atomicAdd(overflow_count, 1)] = i;
         return;
     }
-    for (int p = lane; p < count; p += 64) cj[p] = cand[(size_t)i * MF_CAP + p];
+    for (int s = 0, base = 0; s < nsub; ++s) {
+        const int c = cand_count[(size_t)i * nsub + s];
+        const int *list = cand + ((size_t)i * nsub + s) * subcap;
+        for (int p = lane; p < c; p += 64) cj[base + p] = list[p];
+        base += c;
+    }
     q[lane] = desc1[(size_t)i * K + lane];
     q[lane + 64] = desc1[(size_t)i * K + lane + 64];
     __syncthreads();
@@ -914,40 +1047,61 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     segs = (tiles_total + tiles_per_seg - 1) / tiles_per_seg;
 
     int err;
-    float *frag = (float *)stx_workspace(ctx, STX_SLOT_M_FRAG, sizeof(float) * ((size_t)n2pad * K + n2pad + 4), &err);
+    // [frag n2pad*K][bnorm n2pad][bmax 1 (+pad)][nh n2pad]
+    float *frag = (float *)stx_workspace(ctx, STX_SLOT_M_FRAG, sizeof(float) * ((size_t)n2pad * K + 2 * (size_t)n2pad + 4), &err);
     if (!frag) return err;
     float *bnorm = frag + (size_t)n2pad * K;
+    float *nh = bnorm + n2pad + 4;
     float *qnorm = (float *)stx_workspace(ctx, STX_SLOT_M_QNORM, sizeof(float) * (size_t)n1, &err);
     if (!qnorm) return err;
-    // [count n1][overflow_count 1 (+pad)][overflow_list n1][cand n1*CAP]
+    // candidate lists: one list of MF_CAP slots per query filled with atomics (fp32 / bf16x3
+    // kernels), or 2 * segs private sub-lists sharing MF_SLOTS_X1 slots per query (x1 kernel)
+    const int nsub = x1 ? 2 * segs : 1;
+    const int subcap = x1 ? MF_SLOTS_X1 / nsub : MF_CAP;
+    // [count n1*nsub][overflow_count 1 (+pad)][overflow_list n1][cand n1*nsub*subcap]
     const size_t n1a = ((size_t)n1 + 3) & ~(size_t)3;
-    int *cnt = (int *)stx_workspace(ctx, STX_SLOT_M_CAND, sizeof(int) * (n1a + 4 + n1a + (size_t)n1 * MF_CAP), &err);
+    const size_t ncnt = ((size_t)n1 * nsub + 3) & ~(size_t)3;
+    int *cnt = (int *)stx_workspace(ctx, STX_SLOT_M_CAND,
+                                    sizeof(int) * (ncnt + 4 + n1a + (size_t)n1 * nsub * subcap), &err);
     if (!cnt) return err;
-    int *ovf_count = cnt + n1a;
+    int *ovf_count = cnt + ncnt;
     int *ovf_list = ovf_count + 4;
     int *cand = ovf_list + n1a;
     hipStream_t st = ctx->stream;
-    STX_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (n1a + 4), st));
+    if (x1)  // the x1 kernel stores every count itself
+        STX_HIP(hipMemsetAsync(ovf_count, 0, sizeof(int) * 4, st));
+    else
+        STX_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (ncnt + 4), st));
     const bool bf16 = algo == STX_MATCH_MFMA_BF16;
-    if (x1)
+    unsigned *bmax = reinterpret_cast<unsigned *>(bnorm + n2pad);
+    if (x1) STX_HIP(hipMemsetAsync(bmax, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(match_norm_kernel, dim3((n2pad + 255) / 256), dim3(256), 0, st, d_desc2, n2, n2pad, bnorm,
+                       x1 ? bmax : (unsigned *)nullptr);
+    if (x1) {
+        hipLaunchKernelGGL(match_neg_half_norm_kernel, dim3((n2pad + 255) / 256), dim3(256), 0, st, bnorm, n2pad, nh);
         hipLaunchKernelGGL(match_prep_frag_bf16x1_kernel, dim3((unsigned)(((size_t)n2pad / MF_JB * 512 + 255) / 256)),
-                           dim3(256), 0, st, d_desc2, n2, n2pad, reinterpret_cast<uint4 *>(frag));
-    else if (bf16)
+                           dim3(256), 0, st, d_desc2, n2, n2pad, bnorm, reinterpret_cast<uint4 *>(frag));
+    } else if (bf16)
         hipLaunchKernelGGL(match_prep_frag_bf16_kernel, dim3((unsigned)(((size_t)n2pad / MF_JB * 512 + 255) / 256)),
                            dim3(256), 0, st, d_desc2, n2, n2pad, reinterpret_cast<uint4 *>(frag));
     else
         hipLaunchKernelGGL(match_prep_frag_kernel, dim3((unsigned)(((size_t)n2pad * K / 4 + 255) / 256)), dim3(256),
                            0, st, d_desc2, n2, n2pad, frag);
-    unsigned *bmax = reinterpret_cast<unsigned *>(bnorm + n2pad);
-    if (x1) STX_HIP(hipMemsetAsync(bmax, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL(match_norm_kernel, dim3((n2pad + 255) / 256), dim3(256), 0, st, d_desc2, n2, n2pad, bnorm,
-                       x1 ? bmax : (unsigned *)nullptr);
     hipLaunchKernelGGL(match_norm_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_desc1, n1, n1, qnorm,
                        (unsigned *)nullptr);
-    if (x1)
-        hipLaunchKernelGGL(match_mfma_bf16x1_kernel, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm,
-                           n1, reinterpret_cast<const uint4 *>(frag), bnorm, reinterpret_cast<const float *>(bmax), n2,
-                           tiles_total, tiles_per_seg, cnt, cand);
+    static int dbg = getenv("STX_X1_DEBUG") ? atoi(getenv("STX_X1_DEBUG")) : 0;
+    if (x1 && dbg == 1)
+        hipLaunchKernelGGL(match_mfma_bf16x1_kernel<1>, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm,
+                           n1, reinterpret_cast<const uint4 *>(frag), nh, reinterpret_cast<const float *>(bmax), n2,
+                           tiles_total, tiles_per_seg, nsub, subcap, cnt, cand);
+    else if (x1 && dbg == 2)
+        hipLaunchKernelGGL(match_mfma_bf16x1_kernel<2>, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm,
+                           n1, reinterpret_cast<const uint4 *>(frag), nh, reinterpret_cast<const float *>(bmax), n2,
+                           tiles_total, tiles_per_seg, nsub, subcap, cnt, cand);
+    else if (x1)
+        hipLaunchKernelGGL(match_mfma_bf16x1_kernel<0>, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm,
+                           n1, reinterpret_cast<const uint4 *>(frag), nh, reinterpret_cast<const float *>(bmax), n2,
+                           tiles_total, tiles_per_seg, nsub, subcap, cnt, cand);
     else if (bf16)
         hipLaunchKernelGGL(match_mfma_bf16_kernel, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm,
                            n1, reinterpret_cast<const uint4 *>(frag), bnorm, n2, tiles_total, tiles_per_seg, cnt,
@@ -956,7 +1110,7 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
         hipLaunchKernelGGL(match_mfma_kernel, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm, n1,
                            frag, bnorm, n2, tiles_total, tiles_per_seg, cnt, cand);
     hipLaunchKernelGGL(match_replay_kernel, dim3(n1), dim3(64), 0, st, d_desc1, d_score1, n1, d_desc2, d_score2,
-                       n2, dist_limit, cnt, cand, ovf_count, ovf_list, d_closest, d_second, d_min_dist,
+                       n2, dist_limit, cnt, cand, nsub, subcap, ovf_count, ovf_list, d_closest, d_second, d_min_dist,
                        d_second_dist, d_status);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
