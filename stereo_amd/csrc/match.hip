@@ -149,7 +149,6 @@ constexpr int MF_TJ = 2;               // row blocks per LDS tile
 constexpr int MF_TILE_ROWS = MF_JB * MF_TJ;
 constexpr int MF_BLOCK_FLOATS = MF_JB * K;  // 4096 floats = 16 KiB per row block
 constexpr int MF_CAP = 256;            // candidates per query that the replay kernel sorts
-constexpr int MF_SLOTS_X1 = 512;       // x1 kernel: slots per query, shared by its private sub-lists
 constexpr float MF_C = 6.103515625e-05f;  // 2^-14 >= 523 * 2^-24
 constexpr float MF_TINY = 1e-37f;      // covers underflow in either computation
 
@@ -596,7 +595,8 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16_kernel(
 // to spare.  The looser bound only lengthens the candidate lists (26 instead of 13 per query
 // on the 200k x 200k benchmark set) while the matrix work drops to a third; the exact replay
 // is unchanged, so the outputs stay bit-identical.
-//   frag: [(jb*8 + s)*64 + lane] uint4 = 8 bf16, 8 KiB per 32-row block, 4 blocks per LDS tile
+//   tile (128 rows, MF_TILE_U4 uint4): 4 blocks of [s*64 + lane] uint4 = 8 bf16 (8 KiB per
+//   32-row block), then the 128 seeds -h of the tile as floats (padded to 1 KiB)
 //
 // The whole bound lives in the accumulator.  With h_j = |b_j|^2 / 2 the MFMA chain of a block
 // starts from C = -h_j instead of 0, so it ends in y_j = a.b_j - h_j = -(|b_j|^2 - 2 a.b_j)/2:
@@ -618,15 +618,18 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16_kernel(
 constexpr float MF_C_X1 = 4.5e-3f;
 constexpr int MF_TJ1 = 4;
 constexpr int MF_TILE_ROWS1 = MF_JB * MF_TJ1;
+constexpr int MF_TILE_U4 = MF_TJ1 * 512 + 64;  // uint4 units per staged tile: fragments + seeds
 
-// -|b_j|^2 / 2 per row of list2 (padding rows 0, unbounded rows +inf = "-h" with h = -inf)
+// -|b_j|^2 / 2 per row of list2 (padding rows 0, unbounded rows +inf = "-h" with h = -inf),
+// written behind the fragments of the row's tile
 __global__ __launch_bounds__(256) void match_neg_half_norm_kernel(const float *__restrict__ bnorm, int npad,
-                                                                   float *__restrict__ nh)
+                                                                   uint4 *__restrict__ frag16)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= npad) return;
     const float s = bnorm[r];
-    nh[r] = s == s ? -0.5f * s : __builtin_inff();
+    float *seeds = reinterpret_cast<float *>(frag16 + (size_t)(r / MF_TILE_ROWS1) * MF_TILE_U4 + MF_TJ1 * 512);
+    seeds[r % MF_TILE_ROWS1] = s == s ? -0.5f * s : __builtin_inff();
 }
 
 __global__ __launch_bounds__(256) void match_prep_frag_bf16x1_kernel(const float *__restrict__ desc2, int n2,
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(256) void match_prep_frag_bf16x1_kernel(const float
         const float4 *row = reinterpret_cast<const float4 *>(desc2 + j * K + 16 * s + 8 * (lane >> 5));
         bf16_split8(row[0], row[1], hi, lo);
     }
-    frag16[idx] = hi;
+    frag16[(jb / MF_TJ1) * MF_TILE_U4 + (jb % MF_TJ1) * 512 + (idx & 511)] = hi;
 }
 
 struct BoundX1 {
@@ -706,11 +709,11 @@ __device__ __forceinline__ void x1_rows(const f32x16 &p, BoundX1 &b)
     }
 }
 
-// rows of this lane in a 32-row block, in accumulator-register order r = 0..15:
-//   j = j0 + (r&3) + 8*(r>>2) + 4*half
-__device__ __forceinline__ f32x16 load_nh(const float *__restrict__ nh, int j0, int half)
+// seeds of this lane's rows of block kb of a staged tile, in accumulator-register order
+// r = 0..15:  j = j0 + (r&3) + 8*(r>>2) + 4*half  (4 broadcast ds_read_b128)
+__device__ __forceinline__ f32x16 load_seeds(const uint4 *tile, int kb, int half)
 {
-    const float4 *p = reinterpret_cast<const float4 *>(nh + j0 + 4 * half);
+    const float4 *p = reinterpret_cast<const float4 *>(tile + MF_TJ1 * 512) + kb * 8 + half;
     f32x16 v;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -734,11 +737,11 @@ template <int DBG>
 __device__ __forceinline__ void x1_close(const f32x16 &acc, BoundX1 &b, bool live, int j0, int half,
                                          int n2, int *__restrict__ list, int subcap)
 {
+    if (DBG & 2) return;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(b.M) : "v"(acc[r]), "v"(acc[r + 1]));
-    if (DBG == 2) return;
     const bool hit = !(b.M < b.T);
-    if (DBG != 1 && __any(hit)) {
+    if (!(DBG & 1) && __any(hit)) {
         if (__any(b.M == __builtin_inff()))
             x1_rows<true>(acc, b);
         else
@@ -776,7 +779,7 @@ __device__ __forceinline__ void x1_block(const uint4 (&f)[8], const bf16x8 (&qh0
     a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, qh0[0], c, 0, 0, 0);
     if (!FIRST) x1_close<DBG>(a1, b1, live1, jprev, half, n2, list1, subcap);
     a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, qh1[0], c, 0, 0, 0);
-    if (!FIRST) {
+    if (!FIRST && !(DBG & 2)) {
         x1_update(b0);
         x1_update(b1);
     }
@@ -788,71 +791,30 @@ __device__ __forceinline__ void x1_block(const uint4 (&f)[8], const bf16x8 (&qh0
     }
 }
 
+// Work distribution.  The (query block, tile of list2) plane is flattened query block major
+// and cut into one contiguous range of `per` tiles per workgroup, so every workgroup does the
+// same amount of matrix work whatever n1 and n2 are, and a query block is cut into few
+// pieces (two when there are more query blocks than workgroups).  Every piece starts with a
+// cold bound -- its first rows are always candidates -- so few pieces also mean few
+// candidates.  Piece p of a query block owns sub-lists 2p and 2p + 1 (one per half-wave).
 template <int DBG>
 __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
     const float *__restrict__ desc1, const float *__restrict__ qnorm, int n1,
-    const uint4 *__restrict__ frag16, const float *__restrict__ nh, const float *__restrict__ bmax, int n2,
-    int tiles_total, int tiles_per_seg, int nsub, int subcap, int *__restrict__ cand_count,
-    int *__restrict__ cand)
+    const uint4 *__restrict__ frag16, const float *__restrict__ bmax, int n2,
+    int tiles_total, long long per, long long flat_total, int nsub, int subcap,
+    int *__restrict__ cand_count, int *__restrict__ cand)
 {
-    __shared__ uint4 tile[2][MF_TJ1 * 512];  // 2 x 32 KiB
+    __shared__ uint4 tile[2][MF_TILE_U4];  // 2 x 33 KiB
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int half = lane >> 5;
     const int col = lane & 31;
-    const int q0i = blockIdx.x * MF_QB + wave * MF_QW + col;
-    const int q1i = q0i + 32;
-    const bool live0 = q0i < n1, live1 = q1i < n1;
-
-    bf16x8 qh0[8], qh1[8];
-    {
-        const float4 *r0 = reinterpret_cast<const float4 *>(desc1 + (size_t)(live0 ? q0i : 0) * K + 8 * half);
-        const float4 *r1 = reinterpret_cast<const float4 *>(desc1 + (size_t)(live1 ? q1i : 0) * K + 8 * half);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            uint4 h, l;
-            bf16_split8(r0[4 * s], r0[4 * s + 1], h, l);
-            if (!live0) h = make_uint4(0, 0, 0, 0);
-            qh0[s] = __builtin_bit_cast(bf16x8, h);
-            bf16_split8(r1[4 * s], r1[4 * s + 1], h, l);
-            if (!live1) h = make_uint4(0, 0, 0, 0);
-            qh1[s] = __builtin_bit_cast(bf16x8, h);
-        }
-    }
-    // e = C (|a|^2 + max |b|^2) + tiny in the units of d~ = |a|^2 - 2y; on y the test
-    // d~_j' + e < d~_j - e reads y_j < y_j' - e.  A non-finite query norm (NaN) makes T NaN:
-    // every row is emitted and the query goes to the exact kernel.
     const float nbmax = *bmax;
-    const float na0 = live0 ? qnorm[q0i] : 0.f;
-    const float na1 = live1 ? qnorm[q1i] : 0.f;
-    BoundX1 b0, b1;
-    b0.e = MF_C_X1 * (na0 + nbmax) + MF_TINY;
-    b1.e = MF_C_X1 * (na1 + nbmax) + MF_TINY;
-    b0.Y = b1.Y = b0.M = b1.M = -__builtin_inff();
-    b0.T = b0.Y - b0.e;
-    b1.T = b1.Y - b1.e;
-    b0.mask = b1.mask = 0;
-    b0.cnt = b1.cnt = 0;
-    const int sub = 2 * blockIdx.y + half;  // this lane's sub-list of its two queries
-    int *count0 = cand_count + (size_t)(live0 ? q0i : 0) * nsub + sub;
-    int *count1 = cand_count + (size_t)(live1 ? q1i : 0) * nsub + sub;
-    int *list0 = cand + ((size_t)(live0 ? q0i : 0) * nsub + sub) * subcap;
-    int *list1 = cand + ((size_t)(live1 ? q1i : 0) * nsub + sub) * subcap;
-
-    const int t_begin = blockIdx.y * tiles_per_seg;
-    const int t_end = min(t_begin + tiles_per_seg, tiles_total);
-    if (t_begin >= t_end) {
-        if (live0) *count0 = 0;
-        if (live1) *count1 = 0;
-        return;
-    }
-    const int ntiles = t_end - t_begin;
-    const int j_last = (tiles_total * MF_TJ1 - 1) * MF_JB;  // first row of the last block of list2
 
     auto stage = [&](int t, int buf) {
-        const uint4 *src = frag16 + (size_t)t * MF_TJ1 * 512;
+        const uint4 *src = frag16 + (size_t)t * MF_TILE_U4;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int chunk = (k * MF_WAVES + wave) * 64;  // uint4 units, 1 KiB per wave-instruction
@@ -860,60 +822,127 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
                 (const __attribute__((address_space(1))) void *)(src + chunk + lane),
                 (__attribute__((address_space(3))) void *)(&tile[buf][chunk]), 16, 0, 0);
         }
+        if (wave == 0)  // the tile's seeds
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + MF_TJ1 * 512 + lane),
+                (__attribute__((address_space(3))) void *)(&tile[buf][MF_TJ1 * 512]), 16, 0, 0);
     };
 
-    // Everything a block needs -- its 8 A fragments (LDS) and its 16 seeds -h (L2) -- is
-    // loaded into registers one whole block (>= 512 matrix cycles) ahead of its MFMA chain; two
-    // register sets alternate.  LDS tiles are double buffered with one barrier per tile, placed
-    // before the tile's last block: by then every wave has its last fragments of this tile in
-    // registers, so the buffer can be refilled (tile + 2) and the next tile's first block read.
-    stage(t_begin, 0);
-    __syncthreads();
-    if (ntiles > 1) stage(t_begin + 1, 1);
-    uint4 fA[8], fB[8];
-    f32x16 cA, cB, a0, a1;
-    load_frag(tile[0] + lane, fA);
-    cA = load_nh(nh, t_begin * MF_TILE_ROWS1, half);
+    long long flat = (long long)blockIdx.x * per;
+    const long long flat_end = flat + per < flat_total ? flat + per : flat_total;
+#pragma unroll 1
+    while (flat < flat_end) {
+        const int qb = (int)(flat / tiles_total);
+        const int t_begin = (int)(flat - (long long)qb * tiles_total);
+        const int t_end = (int)((long long)t_begin + (flat_end - flat) < (long long)tiles_total
+                                    ? (long long)t_begin + (flat_end - flat) : (long long)tiles_total);
+        const int ntiles = t_end - t_begin;
+        flat += ntiles;
+        // pieces of a query block are numbered from the first workgroup that touches it
+        const int piece = (int)blockIdx.x - (int)(((long long)qb * tiles_total) / per);
+
+        const int q0i = qb * MF_QB + wave * MF_QW + col;
+        const int q1i = q0i + 32;
+        const bool live0 = q0i < n1, live1 = q1i < n1;
+        bf16x8 qh0[8], qh1[8];
+        {
+            const float4 *r0 = reinterpret_cast<const float4 *>(desc1 + (size_t)(live0 ? q0i : 0) * K + 8 * half);
+            const float4 *r1 = reinterpret_cast<const float4 *>(desc1 + (size_t)(live1 ? q1i : 0) * K + 8 * half);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                uint4 h, l;
+                bf16_split8(r0[4 * s], r0[4 * s + 1], h, l);
+                if (!live0) h = make_uint4(0, 0, 0, 0);
+                qh0[s] = __builtin_bit_cast(bf16x8, h);
+                bf16_split8(r1[4 * s], r1[4 * s + 1], h, l);
+                if (!live1) h = make_uint4(0, 0, 0, 0);
+                qh1[s] = __builtin_bit_cast(bf16x8, h);
+            }
+        }
+        // e = C (|a|^2 + max |b|^2) + tiny in the units of d~ = |a|^2 - 2y; on y the test
+        // d~_j' + e < d~_j - e reads y_j < y_j' - e.  A non-finite query norm (NaN) makes T NaN:
+        // every row is emitted and the query goes to the exact kernel.
+        const float na0 = live0 ? qnorm[q0i] : 0.f;
+        const float na1 = live1 ? qnorm[q1i] : 0.f;
+        BoundX1 b0, b1;
+        b0.e = MF_C_X1 * (na0 + nbmax) + MF_TINY;
+        b1.e = MF_C_X1 * (na1 + nbmax) + MF_TINY;
+        b0.Y = b1.Y = b0.M = b1.M = -__builtin_inff();
+        b0.T = b0.Y - b0.e;
+        b1.T = b1.Y - b1.e;
+        b0.mask = b1.mask = 0;
+        b0.cnt = b1.cnt = 0;
+        const int sub = 2 * piece + half;  // this lane's sub-list of its two queries
+        int *count0 = cand_count + (size_t)(live0 ? q0i : 0) * nsub + sub;
+        int *count1 = cand_count + (size_t)(live1 ? q1i : 0) * nsub + sub;
+        int *list0 = cand + ((size_t)(live0 ? q0i : 0) * nsub + sub) * subcap;
+        int *list1 = cand + ((size_t)(live1 ? q1i : 0) * nsub + sub) * subcap;
+
+        // Everything a block needs -- its 8 A fragments and its 16 seeds -h, both from the
+        // staged tile -- is read into registers one whole block (>= 512 matrix cycles) ahead of
+        // its MFMA chain; two register sets alternate.  The loop has no global loads besides
+        // the staging (a younger global load that is waited for would drag the staging loads'
+        // latency in).  LDS tiles are double buffered with one barrier per tile, placed before
+        // the tile's last block: by then every wave has its last fragments of this tile in
+        // registers, so the buffer can be refilled (tile + 2) and the next tile's first block
+        // read.  (After the last tile's barrier nobody reads LDS any more, so the next piece
+        // may stage at once.)
+        stage(t_begin, 0);
+        __syncthreads();
+        if (ntiles > 1) stage(t_begin + 1, 1);
+        uint4 fA[8], fB[8];
+        f32x16 cA, cB, a0, a1;
+        load_frag(tile[0] + lane, fA);
+        cA = load_seeds(tile[0], 0, half);
 #define X1_BLOCK(FIRST, F, C, JPREV)                                                                   \
     x1_block<FIRST, DBG>(F, qh0, qh1, C, a0, a1, b0, b1, live0, live1, JPREV, half, n2, list0, list1, subcap)
-    for (int tt = 0; tt < ntiles; ++tt) {
-        const int buf = tt & 1;
-        const uint4 *bf = tile[buf] + lane;
-        const int j0 = (t_begin + tt) * MF_TILE_ROWS1;
-        load_frag(bf + 512, fB);
-        cB = load_nh(nh, j0 + MF_JB, half);
-        __builtin_amdgcn_sched_barrier(0);
-        if (tt == 0)
-            X1_BLOCK(true, fA, cA, 0);
-        else
-            X1_BLOCK(false, fA, cA, j0 - MF_JB);
-        load_frag(bf + 1024, fA);
-        cA = load_nh(nh, j0 + 2 * MF_JB, half);
-        __builtin_amdgcn_sched_barrier(0);
-        X1_BLOCK(false, fB, cB, j0);
-        load_frag(bf + 1536, fB);
-        cB = load_nh(nh, j0 + 3 * MF_JB, half);
-        __builtin_amdgcn_sched_barrier(0);
-        X1_BLOCK(false, fA, cA, j0 + MF_JB);
-        __syncthreads();  // tile tt + 1 has landed; nobody reads tile tt from LDS any more
-        if (tt + 2 < ntiles) stage(t_begin + tt + 2, buf);
-        if (tt + 1 < ntiles) load_frag(tile[buf ^ 1] + lane, fA);
-        cA = load_nh(nh, min(j0 + 4 * MF_JB, j_last), half);
-        __builtin_amdgcn_sched_barrier(0);
-        X1_BLOCK(false, fB, cB, j0 + 2 * MF_JB);
-    }
+#pragma unroll 1
+        for (int tt = 0; tt < ntiles; ++tt) {
+            const int buf = tt & 1;
+            const uint4 *bf = tile[buf] + lane;
+            const int j0 = (t_begin + tt) * MF_TILE_ROWS1;
+            load_frag(bf + 512, fB);
+            cB = load_seeds(tile[buf], 1, half);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tt == 0)
+                X1_BLOCK(true, fA, cA, 0);
+            else
+                X1_BLOCK(false, fA, cA, j0 - MF_JB);
+            load_frag(bf + 1024, fA);
+            cA = load_seeds(tile[buf], 2, half);
+            __builtin_amdgcn_sched_barrier(0);
+            X1_BLOCK(false, fB, cB, j0);
+            load_frag(bf + 1536, fB);
+            cB = load_seeds(tile[buf], 3, half);
+            __builtin_amdgcn_sched_barrier(0);
+            X1_BLOCK(false, fA, cA, j0 + MF_JB);
+            __syncthreads();  // tile tt + 1 has landed; nobody reads tile tt from LDS any more
+            if (tt + 2 < ntiles) stage(t_begin + tt + 2, buf);
+            if (tt + 1 < ntiles) {
+                load_frag(tile[buf ^ 1] + lane, fA);
+                cA = load_seeds(tile[buf ^ 1], 0, half);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            X1_BLOCK(false, fB, cB, j0 + 2 * MF_JB);
+        }
 #undef X1_BLOCK
-    {   // drain: the last block
-        const int j0 = (t_end - 1) * MF_TILE_ROWS1 + 3 * MF_JB;
-        x1_close<DBG>(a0, b0, live0, j0, half, n2, list0, subcap);
-        x1_close<DBG>(a1, b1, live1, j0, half, n2, list1, subcap);
+        {   // drain: the last block
+            const int j0 = (t_end - 1) * MF_TILE_ROWS1 + 3 * MF_JB;
+            x1_close<DBG>(a0, b0, live0, j0, half, n2, list0, subcap);
+            x1_close<DBG>(a1, b1, live1, j0, half, n2, list1, subcap);
+        }
+        if (live0) *count0 = b0.cnt;
+        if (live1) *count1 = b1.cnt;
+        if (DBG && b0.M + b1.M + b0.Y + b1.Y == 123.456f) cand[0] = 1;
     }
-    if (live0) *count0 = b0.cnt;
-    if (live1) *count1 = b1.cnt;
-    if (DBG && b0.M + b1.M + b0.Y + b1.Y == 123.456f) cand[0] = 1;
 }
 
-// Phase 2: one wave per query.
+// Phase 2: exact replay, RP_G queries per wave (RP_L lanes each).  A query has a few tens of
+// candidates, so a whole wave per query would leave most lanes idle through the 384-operation
+// distance chains and all but one through the final scan.
+constexpr int RP_G = 4;
+constexpr int RP_L = 64 / RP_G;
+
 __global__ __launch_bounds__(64) void match_replay_kernel(
     const float *__restrict__ desc1, const float *__restrict__ score1, int n1,
     const float *__restrict__ desc2, const float *__restrict__ score2, int n2, float dist_limit,
@@ -922,37 +951,45 @@ __global__ __launch_bounds__(64) void match_replay_kernel(
     int *__restrict__ overflow_list, int32_t *__restrict__ closest_out, int32_t *__restrict__ second_out,
     float *__restrict__ min_dist_out, float *__restrict__ second_dist_out, uint8_t *__restrict__ status_out)
 {
-    __shared__ int cj[MF_CAP];
-    __shared__ int sj[MF_CAP];
-    __shared__ float dist[MF_CAP];
-    __shared__ float q[K];
-    const int i = blockIdx.x;
-    const int lane = threadIdx.x;
+    __shared__ int cj_[RP_G][MF_CAP];
+    __shared__ int sj_[RP_G][MF_CAP];
+    __shared__ float dist_[RP_G][MF_CAP];
+    __shared__ float q_[RP_G][K];
+    const int g = threadIdx.x / RP_L;
+    const int l = threadIdx.x % RP_L;
+    const int i = blockIdx.x * RP_G + g;
+    int *cj = cj_[g], *sj = sj_[g];
+    float *dist = dist_[g], *q = q_[g];
     // the query's candidates: nsub sub-lists of at most subcap entries (one list for the atomic
     // kernels, one per (segment, half) for the x1 kernel)
     int count = 0;
-    bool overflow = false;
-    for (int s = 0; s < nsub; ++s) {
-        const int c = cand_count[(size_t)i * nsub + s];
-        overflow |= c > subcap;
-        count += c;
+    bool live = i < n1;
+    if (live) {
+        bool overflow = false;
+        for (int s = 0; s < nsub; ++s) {
+            const int c = cand_count[(size_t)i * nsub + s];
+            overflow |= c > subcap;
+            count += c;
+        }
+        if (overflow || count > MF_CAP) {  // too many near-ties: exact scan for this query
+            if (l == 0) overflow_list[atomicAdd(overflow_count, 1)] = i;
+            live = false;
+        }
     }
-    if (overflow || count > MF_CAP) {  // too many near-ties: exact scan for this query
-        if (lane == 0) overflow_list[atomicAdd(overflow_count, 1)] = i;
-        return;
+    if (!live) count = 0;
+    if (live) {
+        for (int s = 0, base = 0; s < nsub; ++s) {
+            const int c = cand_count[(size_t)i * nsub + s];
+            const int *list = cand + ((size_t)i * nsub + s) * subcap;
+            for (int p = l; p < c; p += RP_L) cj[base + p] = list[p];
+            base += c;
+        }
+        for (int k = l; k < K; k += RP_L) q[k] = desc1[(size_t)i * K + k];
     }
-    for (int s = 0, base = 0; s < nsub; ++s) {
-        const int c = cand_count[(size_t)i * nsub + s];
-        const int *list = cand + ((size_t)i * nsub + s) * subcap;
-        for (int p = lane; p < c; p += 64) cj[base + p] = list[p];
-        base += c;
-    }
-    q[lane] = desc1[(size_t)i * K + lane];
-    q[lane + 64] = desc1[(size_t)i * K + lane + 64];
     __syncthreads();
     // rank sort (candidate indices are distinct)
 #pragma unroll 1
-    for (int p = lane; p < count; p += 64) {
+    for (int p = l; p < count; p += RP_L) {
         const int j = cj[p];
         int rank = 0;
 #pragma unroll 4
@@ -961,22 +998,23 @@ __global__ __launch_bounds__(64) void match_replay_kernel(
     }
     __syncthreads();
 #pragma unroll 1
-    for (int p = lane; p < count; p += 64) {
+    for (int p = l; p < count; p += RP_L) {
         const float4 *b = reinterpret_cast<const float4 *>(desc2 + (size_t)sj[p] * K);
         float norm = 0.0f;
-#pragma unroll 4
+#pragma unroll 8
         for (int k4 = 0; k4 < K / 4; ++k4) {  // reference order: k ascending, one accumulator
             const float4 bv = b[k4];
+            const float4 qv = reinterpret_cast<const float4 *>(q)[k4];
             float d;
-            d = q[4 * k4 + 0] - bv.x; norm = norm + d * d;
-            d = q[4 * k4 + 1] - bv.y; norm = norm + d * d;
-            d = q[4 * k4 + 2] - bv.z; norm = norm + d * d;
-            d = q[4 * k4 + 3] - bv.w; norm = norm + d * d;
+            d = qv.x - bv.x; norm = norm + d * d;
+            d = qv.y - bv.y; norm = norm + d * d;
+            d = qv.z - bv.z; norm = norm + d * d;
+            d = qv.w - bv.w; norm = norm + d * d;
         }
         dist[p] = sqrtf(norm);
     }
     __syncthreads();
-    if (lane != 0) return;
+    if (l != 0 || !live) return;
     int closest = -1, second = -1;
     float min_dist = -1.0f, second_dist = -1.0f;
     if (count > 0) {  // sj[0] is list2[0]: taken unconditionally (minDist == -1, Features.cpp:1041)
@@ -1030,8 +1068,10 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     // ---- MFMA prefilter + replay ------------------------------------------
     const bool x1 = algo == STX_MATCH_MFMA_BF16X1;
     const int tile_rows = x1 ? MF_TILE_ROWS1 : MF_TILE_ROWS;
-    const int n2pad = (n2 + tile_rows - 1) / tile_rows * tile_rows;
-    const int tiles_total = n2pad / tile_rows;
+    int tiles_total = (n2 + tile_rows - 1) / tile_rows;
+    // x1: the workgroups' ranges start at multiples of tiles_total / 32 (see below)
+    if (x1 && tiles_total >= 256) tiles_total = (tiles_total + 31) / 32 * 32;
+    const int n2pad = tiles_total * tile_rows;
     const int qblocks = (n1 + MF_QB - 1) / MF_QB;
     // segments of list2: fill the CUs evenly (2 workgroups per CU), keep segments long
     const int slots = 2 * (ctx->num_cus > 0 ? ctx->num_cus : 256);
@@ -1047,17 +1087,31 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     segs = (tiles_total + tiles_per_seg - 1) / tiles_per_seg;
 
     int err;
-    // [frag n2pad*K][bnorm n2pad][bmax 1 (+pad)][nh n2pad]
-    float *frag = (float *)stx_workspace(ctx, STX_SLOT_M_FRAG, sizeof(float) * ((size_t)n2pad * K + 2 * (size_t)n2pad + 4), &err);
+    // [frag: n2pad*K floats, or x1 tiles of MF_TILE_U4 uint4][bnorm n2pad][bmax 1 (+pad)]
+    const size_t frag_floats = x1 ? (size_t)tiles_total * MF_TILE_U4 * 4 : (size_t)n2pad * K;
+    float *frag = (float *)stx_workspace(ctx, STX_SLOT_M_FRAG, sizeof(float) * (frag_floats + (size_t)n2pad + 4), &err);
     if (!frag) return err;
-    float *bnorm = frag + (size_t)n2pad * K;
-    float *nh = bnorm + n2pad + 4;
+    float *bnorm = frag + frag_floats;
     float *qnorm = (float *)stx_workspace(ctx, STX_SLOT_M_QNORM, sizeof(float) * (size_t)n1, &err);
     if (!qnorm) return err;
+    // x1 kernel: one contiguous range of `per` tiles of the flattened (query block, tile) plane
+    // per workgroup, 2 workgroups per CU; a query block is cut into at most max_pieces pieces
+    const long long flat_total = (long long)qblocks * tiles_total;
+    long long per = (flat_total + slots - 1) / slots;
+    if (per < (tiles_total + 6) / 7) per = (tiles_total + 6) / 7;
+    // Workgroups b and b + 8 share an XCD and its L2.  With every range starting at a multiple
+    // of tiles_total / 32, the 64 workgroups of an XCD stream list2 at no more than 4 distinct
+    // positions, in step, so all but the first reader of a tile hit in L2.
+    if (tiles_total % 32 == 0 && tiles_total >= 256) {
+        const long long u = tiles_total / 32;
+        per = (per + u - 1) / u * u;
+    }
+    const int x1_wgs = (int)((flat_total + per - 1) / per);
+    const int max_pieces = (int)((tiles_total + per - 1) / per) + 1;
     // candidate lists: one list of MF_CAP slots per query filled with atomics (fp32 / bf16x3
-    // kernels), or 2 * segs private sub-lists sharing MF_SLOTS_X1 slots per query (x1 kernel)
-    const int nsub = x1 ? 2 * segs : 1;
-    const int subcap = x1 ? MF_SLOTS_X1 / nsub : MF_CAP;
+    // kernels), or two private sub-lists per piece (x1 kernel)
+    const int nsub = x1 ? 2 * max_pieces : 1;
+    const int subcap = x1 ? (nsub <= 8 ? 128 : nsub <= 16 ? 64 : 32) : MF_CAP;
     // [count n1*nsub][overflow_count 1 (+pad)][overflow_list n1][cand n1*nsub*subcap]
     const size_t n1a = ((size_t)n1 + 3) & ~(size_t)3;
     const size_t ncnt = ((size_t)n1 * nsub + 3) & ~(size_t)3;
@@ -1068,17 +1122,16 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     int *ovf_list = ovf_count + 4;
     int *cand = ovf_list + n1a;
     hipStream_t st = ctx->stream;
-    if (x1)  // the x1 kernel stores every count itself
-        STX_HIP(hipMemsetAsync(ovf_count, 0, sizeof(int) * 4, st));
-    else
-        STX_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (ncnt + 4), st));
+    // (the x1 kernel stores the counts of the sub-lists it uses; the others must read 0)
+    STX_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (ncnt + 4), st));
     const bool bf16 = algo == STX_MATCH_MFMA_BF16;
     unsigned *bmax = reinterpret_cast<unsigned *>(bnorm + n2pad);
     if (x1) STX_HIP(hipMemsetAsync(bmax, 0, sizeof(unsigned), st));
     hipLaunchKernelGGL(match_norm_kernel, dim3((n2pad + 255) / 256), dim3(256), 0, st, d_desc2, n2, n2pad, bnorm,
                        x1 ? bmax : (unsigned *)nullptr);
     if (x1) {
-        hipLaunchKernelGGL(match_neg_half_norm_kernel, dim3((n2pad + 255) / 256), dim3(256), 0, st, bnorm, n2pad, nh);
+        hipLaunchKernelGGL(match_neg_half_norm_kernel, dim3((n2pad + 255) / 256), dim3(256), 0, st, bnorm, n2pad,
+                           reinterpret_cast<uint4 *>(frag));
         hipLaunchKernelGGL(match_prep_frag_bf16x1_kernel, dim3((unsigned)(((size_t)n2pad / MF_JB * 512 + 255) / 256)),
                            dim3(256), 0, st, d_desc2, n2, n2pad, bnorm, reinterpret_cast<uint4 *>(frag));
     } else if (bf16)
@@ -1090,18 +1143,17 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     hipLaunchKernelGGL(match_norm_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_desc1, n1, n1, qnorm,
                        (unsigned *)nullptr);
     static int dbg = getenv("STX_X1_DEBUG") ? atoi(getenv("STX_X1_DEBUG")) : 0;
-    if (x1 && dbg == 1)
-        hipLaunchKernelGGL(match_mfma_bf16x1_kernel<1>, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm,
-                           n1, reinterpret_cast<const uint4 *>(frag), nh, reinterpret_cast<const float *>(bmax), n2,
-                           tiles_total, tiles_per_seg, nsub, subcap, cnt, cand);
-    else if (x1 && dbg == 2)
-        hipLaunchKernelGGL(match_mfma_bf16x1_kernel<2>, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm,
-                           n1, reinterpret_cast<const uint4 *>(frag), nh, reinterpret_cast<const float *>(bmax), n2,
-                           tiles_total, tiles_per_seg, nsub, subcap, cnt, cand);
+#define X1_DBG_LAUNCH(D)                                                                                          \
+    else if (x1 && dbg == D) hipLaunchKernelGGL(match_mfma_bf16x1_kernel<D>, dim3(x1_wgs), dim3(MF_WAVES * 64),       \
+                                                0, st, d_desc1, qnorm, n1, reinterpret_cast<const uint4 *>(frag),   \
+                                                reinterpret_cast<const float *>(bmax), n2, tiles_total, per,        \
+                                                flat_total, nsub, subcap, cnt, cand)
+    if (false) {}
+    X1_DBG_LAUNCH(1);
     else if (x1)
-        hipLaunchKernelGGL(match_mfma_bf16x1_kernel<0>, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm,
-                           n1, reinterpret_cast<const uint4 *>(frag), nh, reinterpret_cast<const float *>(bmax), n2,
-                           tiles_total, tiles_per_seg, nsub, subcap, cnt, cand);
+        hipLaunchKernelGGL(match_mfma_bf16x1_kernel<0>, dim3(x1_wgs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm,
+                           n1, reinterpret_cast<const uint4 *>(frag), reinterpret_cast<const float *>(bmax), n2,
+                           tiles_total, per, flat_total, nsub, subcap, cnt, cand);
     else if (bf16)
         hipLaunchKernelGGL(match_mfma_bf16_kernel, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm,
                            n1, reinterpret_cast<const uint4 *>(frag), bnorm, n2, tiles_total, tiles_per_seg, cnt,
@@ -1109,7 +1161,7 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     else
         hipLaunchKernelGGL(match_mfma_kernel, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm, n1,
                            frag, bnorm, n2, tiles_total, tiles_per_seg, cnt, cand);
-    hipLaunchKernelGGL(match_replay_kernel, dim3(n1), dim3(64), 0, st, d_desc1, d_score1, n1, d_desc2, d_score2,
+    hipLaunchKernelGGL(match_replay_kernel, dim3((n1 + RP_G - 1) / RP_G), dim3(64), 0, st, d_desc1, d_score1, n1, d_desc2, d_score2,
                        n2, dist_limit, cnt, cand, nsub, subcap, ovf_count, ovf_list, d_closest, d_second, d_min_dist,
                        d_second_dist, d_status);
     hipError_t e = hipGetLastError();
