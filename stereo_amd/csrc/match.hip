@@ -619,6 +619,8 @@ constexpr float MF_C_X1 = 4.5e-3f;
 constexpr int MF_TJ1 = 4;
 constexpr int MF_TILE_ROWS1 = MF_JB * MF_TJ1;
 constexpr int MF_TILE_U4 = MF_TJ1 * 512 + 64;  // uint4 units per staged tile: fragments + seeds
+constexpr int X1_WAVES = 8;                    // waves per workgroup: one workgroup per CU, 2 waves per SIMD
+constexpr int X1_QB = X1_WAVES * MF_QW;        // queries per workgroup
 
 // -|b_j|^2 / 2 per row of list2 (padding rows 0, unbounded rows +inf = "-h" with h = -inf),
 // written behind the fragments of the row's tile
@@ -733,15 +735,13 @@ __device__ __forceinline__ void load_frag(const uint4 *bf, uint4 (&f)[8])
 // Close one 32-query chain of the block whose y values are still in acc: fold them into
 // b.M; if some lane of the wave may hold a record, run the per-row pass and append the
 // flagged rows.  Afterwards acc may be overwritten.
-template <int DBG>
 __device__ __forceinline__ void x1_close(const f32x16 &acc, BoundX1 &b, bool live, int j0, int half,
                                          int n2, int *__restrict__ list, int subcap)
 {
-    if (DBG & 2) return;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(b.M) : "v"(acc[r]), "v"(acc[r + 1]));
     const bool hit = !(b.M < b.T);
-    if (!(DBG & 1) && __any(hit)) {
+    if (__any(hit)) {
         if (__any(b.M == __builtin_inff()))
             x1_rows<true>(acc, b);
         else
@@ -768,18 +768,18 @@ __device__ __forceinline__ void x1_update(BoundX1 &b)
 // One 32-row block: 16 MFMAs into (a0, a1), both chains starting from c = -h.  Unless FIRST,
 // (a0, a1) still hold the previous block (rows from jprev): each chain is closed right before
 // its first MFMA overwrites it, so the matrix pipe only waits for eight v_max3 per chain.
-template <bool FIRST, int DBG>
+template <bool FIRST>
 __device__ __forceinline__ void x1_block(const uint4 (&f)[8], const bf16x8 (&qh0)[8], const bf16x8 (&qh1)[8],
                                          const f32x16 &c, f32x16 &a0, f32x16 &a1, BoundX1 &b0, BoundX1 &b1,
                                          bool live0, bool live1, int jprev, int half, int n2,
                                          int *__restrict__ list0, int *__restrict__ list1, int subcap)
 {
     const bf16x8 f0 = __builtin_bit_cast(bf16x8, f[0]);
-    if (!FIRST) x1_close<DBG>(a0, b0, live0, jprev, half, n2, list0, subcap);
+    if (!FIRST) x1_close(a0, b0, live0, jprev, half, n2, list0, subcap);
     a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, qh0[0], c, 0, 0, 0);
-    if (!FIRST) x1_close<DBG>(a1, b1, live1, jprev, half, n2, list1, subcap);
+    if (!FIRST) x1_close(a1, b1, live1, jprev, half, n2, list1, subcap);
     a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, qh1[0], c, 0, 0, 0);
-    if (!FIRST && !(DBG & 2)) {
+    if (!FIRST) {
         x1_update(b0);
         x1_update(b1);
     }
@@ -797,8 +797,7 @@ __device__ __forceinline__ void x1_block(const uint4 (&f)[8], const bf16x8 (&qh0
 // pieces (two when there are more query blocks than workgroups).  Every piece starts with a
 // cold bound -- its first rows are always candidates -- so few pieces also mean few
 // candidates.  Piece p of a query block owns sub-lists 2p and 2p + 1 (one per half-wave).
-template <int DBG>
-__global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
+__global__ __launch_bounds__(X1_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
     const float *__restrict__ desc1, const float *__restrict__ qnorm, int n1,
     const uint4 *__restrict__ frag16, const float *__restrict__ bmax, int n2,
     int tiles_total, long long per, long long flat_total, int nsub, int subcap,
@@ -816,8 +815,8 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
     auto stage = [&](int t, int buf) {
         const uint4 *src = frag16 + (size_t)t * MF_TILE_U4;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int chunk = (k * MF_WAVES + wave) * 64;  // uint4 units, 1 KiB per wave-instruction
+        for (int k = 0; k < 32 / X1_WAVES; ++k) {
+            const int chunk = (k * X1_WAVES + wave) * 64;  // uint4 units, 1 KiB per wave-instruction
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(src + chunk + lane),
                 (__attribute__((address_space(3))) void *)(&tile[buf][chunk]), 16, 0, 0);
@@ -841,7 +840,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
         // pieces of a query block are numbered from the first workgroup that touches it
         const int piece = (int)blockIdx.x - (int)(((long long)qb * tiles_total) / per);
 
-        const int q0i = qb * MF_QB + wave * MF_QW + col;
+        const int q0i = qb * X1_QB + wave * MF_QW + col;
         const int q1i = q0i + 32;
         const bool live0 = q0i < n1, live1 = q1i < n1;
         bf16x8 qh0[8], qh1[8];
@@ -895,7 +894,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
         load_frag(tile[0] + lane, fA);
         cA = load_seeds(tile[0], 0, half);
 #define X1_BLOCK(FIRST, F, C, JPREV)                                                                   \
-    x1_block<FIRST, DBG>(F, qh0, qh1, C, a0, a1, b0, b1, live0, live1, JPREV, half, n2, list0, list1, subcap)
+    x1_block<FIRST>(F, qh0, qh1, C, a0, a1, b0, b1, live0, live1, JPREV, half, n2, list0, list1, subcap)
 #pragma unroll 1
         for (int tt = 0; tt < ntiles; ++tt) {
             const int buf = tt & 1;
@@ -928,12 +927,11 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
 #undef X1_BLOCK
         {   // drain: the last block
             const int j0 = (t_end - 1) * MF_TILE_ROWS1 + 3 * MF_JB;
-            x1_close<DBG>(a0, b0, live0, j0, half, n2, list0, subcap);
-            x1_close<DBG>(a1, b1, live1, j0, half, n2, list1, subcap);
+            x1_close(a0, b0, live0, j0, half, n2, list0, subcap);
+            x1_close(a1, b1, live1, j0, half, n2, list1, subcap);
         }
         if (live0) *count0 = b0.cnt;
         if (live1) *count1 = b1.cnt;
-        if (DBG && b0.M + b1.M + b0.Y + b1.Y == 123.456f) cand[0] = 1;
     }
 }
 
@@ -1072,9 +1070,9 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     // x1: the workgroups' ranges start at multiples of tiles_total / 32 (see below)
     if (x1 && tiles_total >= 256) tiles_total = (tiles_total + 31) / 32 * 32;
     const int n2pad = tiles_total * tile_rows;
-    const int qblocks = (n1 + MF_QB - 1) / MF_QB;
+    const int qblocks = x1 ? (n1 + X1_QB - 1) / X1_QB : (n1 + MF_QB - 1) / MF_QB;
     // segments of list2: fill the CUs evenly (2 workgroups per CU), keep segments long
-    const int slots = 2 * (ctx->num_cus > 0 ? ctx->num_cus : 256);
+    const int slots = (x1 ? 1 : 2) * (ctx->num_cus > 0 ? ctx->num_cus : 256);
     int segs = 1;
     double best_eff = 0;
     for (int s = 1; s <= 6; ++s) {
@@ -1142,16 +1140,8 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
                            0, st, d_desc2, n2, n2pad, frag);
     hipLaunchKernelGGL(match_norm_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_desc1, n1, n1, qnorm,
                        (unsigned *)nullptr);
-    static int dbg = getenv("STX_X1_DEBUG") ? atoi(getenv("STX_X1_DEBUG")) : 0;
-#define X1_DBG_LAUNCH(D)                                                                                          \
-    else if (x1 && dbg == D) hipLaunchKernelGGL(match_mfma_bf16x1_kernel<D>, dim3(x1_wgs), dim3(MF_WAVES * 64),       \
-                                                0, st, d_desc1, qnorm, n1, reinterpret_cast<const uint4 *>(frag),   \
-                                                reinterpret_cast<const float *>(bmax), n2, tiles_total, per,        \
-                                                flat_total, nsub, subcap, cnt, cand)
-    if (false) {}
-    X1_DBG_LAUNCH(1);
-    else if (x1)
-        hipLaunchKernelGGL(match_mfma_bf16x1_kernel<0>, dim3(x1_wgs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm,
+    if (x1)
+        hipLaunchKernelGGL(match_mfma_bf16x1_kernel, dim3(x1_wgs), dim3(X1_WAVES * 64), 0, st, d_desc1, qnorm,
                            n1, reinterpret_cast<const uint4 *>(frag), reinterpret_cast<const float *>(bmax), n2,
                            tiles_total, per, flat_total, nsub, subcap, cnt, cand);
     else if (bf16)
