@@ -688,26 +688,24 @@ __device__ __forceinline__ void x1_test(BoundX1 &b, float y)
         : "+v"(b.mask) : "v"(y), "v"(b.T) : "vcc");
 }
 
-// per-row pass over one block (rare): the bound is refreshed after every pair of rows, i.e.
-// the second row of a pair is tested against a slightly stale -- lower, hence still
-// conservative -- bound.  y = +inf marks an unbounded row: emitted, never part of Y
-// (SPECIAL: some lane of the wave has such a row in this block).
+// per-row pass over one block (rare): every row is tested against the bound the block
+// started with (rows that a record earlier in the same block would have excluded are kept:
+// a slightly larger superset for 16 fewer dependent instructions).  y = +inf marks an
+// unbounded row: emitted, never part of Y (SPECIAL: some lane of the wave has such a row in
+// this block; b.M is then rebuilt from the finite values).
 template <bool SPECIAL>
 __device__ __forceinline__ void x1_rows(const f32x16 &p, BoundX1 &b)
 {
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        const float ya = p[r], yb = p[r + 1];
-        x1_test(b, ya);
-        x1_test(b, yb);
-        if (SPECIAL) {
-            const float fa = ya < __builtin_inff() ? ya : -__builtin_inff();
-            const float fb = yb < __builtin_inff() ? yb : -__builtin_inff();
-            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(b.Y) : "v"(fa), "v"(fb));
-        } else {
-            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(b.Y) : "v"(ya), "v"(yb));
+    for (int r = 0; r < 16; ++r) x1_test(b, p[r]);
+    if (SPECIAL) {
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float f = p[r] < __builtin_inff() ? p[r] : -__builtin_inff();
+            asm("v_max_f32 %0, %0, %1" : "+v"(m) : "v"(f));
         }
-        b.T = b.Y - b.e;
+        b.M = m;
     }
 }
 
@@ -732,14 +730,11 @@ __device__ __forceinline__ void load_frag(const uint4 *bf, uint4 (&f)[8])
     for (int s = 0; s < 8; ++s) f[s] = bf[s * 64];
 }
 
-// Close one 32-query chain of the block whose y values are still in acc: fold them into
-// b.M; if some lane of the wave may hold a record, run the per-row pass and append the
-// flagged rows.  Afterwards acc may be overwritten.
+// Close one 32-query chain of a block whose 16 y values (acc) have been folded into b.M: if
+// some lane of the wave may hold a record, run the per-row pass and append the flagged rows.
 __device__ __forceinline__ void x1_close(const f32x16 &acc, BoundX1 &b, bool live, int j0, int half,
                                          int n2, int *__restrict__ list, int subcap)
 {
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(b.M) : "v"(acc[r]), "v"(acc[r + 1]));
     const bool hit = !(b.M < b.T);
     if (__any(hit)) {
         if (__any(b.M == __builtin_inff()))
@@ -749,7 +744,6 @@ __device__ __forceinline__ void x1_close(const f32x16 &acc, BoundX1 &b, bool liv
         const unsigned k = live ? b.mask : 0u;
         if (__any(k != 0u)) x1_emit(k, b.cnt, list, subcap, j0, half, n2);
         b.mask = 0;
-        b.M = -__builtin_inff();
     }
 }
 
@@ -765,29 +759,44 @@ __device__ __forceinline__ void x1_update(BoundX1 &b)
     b.M = -__builtin_inff();
 }
 
-// One 32-row block: 16 MFMAs into (a0, a1), both chains starting from c = -h.  Unless FIRST,
-// (a0, a1) still hold the previous block (rows from jprev): each chain is closed right before
-// its first MFMA overwrites it, so the matrix pipe only waits for eight v_max3 per chain.
+// One 32-row block: 16 MFMAs into (x0, x1), both chains starting from c = the block's seeds
+// -h.  Unless FIRST, (p0, p1) hold the previous block (rows from jprev): it is folded and closed
+// between the first MFMAs, off the matrix pipe's critical path.  As soon as the two first
+// MFMAs have read c, the seeds of the NEXT block (block seeds_kb of the staged tile at seeds)
+// are read into it.
 template <bool FIRST>
 __device__ __forceinline__ void x1_block(const uint4 (&f)[8], const bf16x8 (&qh0)[8], const bf16x8 (&qh1)[8],
-                                         const f32x16 &c, f32x16 &a0, f32x16 &a1, BoundX1 &b0, BoundX1 &b1,
+                                         f32x16 &x0, f32x16 &x1, const f32x16 &p0, const f32x16 &p1, f32x16 &c,
+                                         const uint4 *seeds, int seeds_kb, BoundX1 &b0, BoundX1 &b1,
                                          bool live0, bool live1, int jprev, int half, int n2,
                                          int *__restrict__ list0, int *__restrict__ list1, int subcap)
 {
-    const bf16x8 f0 = __builtin_bit_cast(bf16x8, f[0]);
-    if (!FIRST) x1_close(a0, b0, live0, jprev, half, n2, list0, subcap);
-    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, qh0[0], c, 0, 0, 0);
-    if (!FIRST) x1_close(a1, b1, live1, jprev, half, n2, list1, subcap);
-    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, qh1[0], c, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const bf16x8 fs = __builtin_bit_cast(bf16x8, f[s]);
+        x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fs, qh0[s], s == 0 ? c : x0, 0, 0, 0);
+        if (!FIRST) {
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(b0.M) : "v"(p0[4 * s]), "v"(p0[4 * s + 1]));
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(b0.M) : "v"(p0[4 * s + 2]), "v"(p0[4 * s + 3]));
+        }
+        x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fs, qh1[s], s == 0 ? c : x1, 0, 0, 0);
+        if (!FIRST) {
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(b1.M) : "v"(p1[4 * s]), "v"(p1[4 * s + 1]));
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(b1.M) : "v"(p1[4 * s + 2]), "v"(p1[4 * s + 3]));
+        }
+        if (s == 0) c = load_seeds(seeds, seeds_kb, half);
+    }
     if (!FIRST) {
+        x1_close(p0, b0, live0, jprev, half, n2, list0, subcap);
+        x1_close(p1, b1, live1, jprev, half, n2, list1, subcap);
         x1_update(b0);
         x1_update(b1);
     }
 #pragma unroll
-    for (int s = 1; s < 8; ++s) {
+    for (int s = 4; s < 8; ++s) {
         const bf16x8 fs = __builtin_bit_cast(bf16x8, f[s]);
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fs, qh0[s], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fs, qh1[s], a1, 0, 0, 0);
+        x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fs, qh0[s], x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fs, qh1[s], x1, 0, 0, 0);
     }
 }
 
@@ -890,45 +899,46 @@ __global__ __launch_bounds__(X1_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
         __syncthreads();
         if (ntiles > 1) stage(t_begin + 1, 1);
         uint4 fA[8], fB[8];
-        f32x16 cA, cB, a0, a1;
+        f32x16 x0, x1, y0, y1;  // two accumulator pairs: one computes while the other is closed
         load_frag(tile[0] + lane, fA);
-        cA = load_seeds(tile[0], 0, half);
-#define X1_BLOCK(FIRST, F, C, JPREV)                                                                   \
-    x1_block<FIRST>(F, qh0, qh1, C, a0, a1, b0, b1, live0, live1, JPREV, half, n2, list0, list1, subcap)
+        f32x16 c = load_seeds(tile[0], 0, half);
+#define X1_BLOCK(FIRST, F, X0, X1, P0, P1, SEEDS, KB, JPREV)                                         \
+    x1_block<FIRST>(F, qh0, qh1, X0, X1, P0, P1, c, SEEDS, KB, b0, b1, live0, live1, JPREV, half, n2, \
+                    list0, list1, subcap)
 #pragma unroll 1
         for (int tt = 0; tt < ntiles; ++tt) {
             const int buf = tt & 1;
             const uint4 *bf = tile[buf] + lane;
             const int j0 = (t_begin + tt) * MF_TILE_ROWS1;
             load_frag(bf + 512, fB);
-            cB = load_seeds(tile[buf], 1, half);
             __builtin_amdgcn_sched_barrier(0);
             if (tt == 0)
-                X1_BLOCK(true, fA, cA, 0);
+                X1_BLOCK(true, fA, x0, x1, y0, y1, tile[buf], 1, 0);
             else
-                X1_BLOCK(false, fA, cA, j0 - MF_JB);
+                X1_BLOCK(false, fA, x0, x1, y0, y1, tile[buf], 1, j0 - MF_JB);
             load_frag(bf + 1024, fA);
-            cA = load_seeds(tile[buf], 2, half);
             __builtin_amdgcn_sched_barrier(0);
-            X1_BLOCK(false, fB, cB, j0);
+            X1_BLOCK(false, fB, y0, y1, x0, x1, tile[buf], 2, j0);
             load_frag(bf + 1536, fB);
-            cB = load_seeds(tile[buf], 3, half);
             __builtin_amdgcn_sched_barrier(0);
-            X1_BLOCK(false, fA, cA, j0 + MF_JB);
+            X1_BLOCK(false, fA, x0, x1, y0, y1, tile[buf], 3, j0 + MF_JB);
             __syncthreads();  // tile tt + 1 has landed; nobody reads tile tt from LDS any more
             if (tt + 2 < ntiles) stage(t_begin + tt + 2, buf);
-            if (tt + 1 < ntiles) {
-                load_frag(tile[buf ^ 1] + lane, fA);
-                cA = load_seeds(tile[buf ^ 1], 0, half);
-            }
+            if (tt + 1 < ntiles) load_frag(tile[buf ^ 1] + lane, fA);
             __builtin_amdgcn_sched_barrier(0);
-            X1_BLOCK(false, fB, cB, j0 + 2 * MF_JB);
+            // (after the piece's last tile the other buffer holds stale seeds: read, never used)
+            X1_BLOCK(false, fB, y0, y1, x0, x1, tile[buf ^ 1], 0, j0 + 2 * MF_JB);
         }
 #undef X1_BLOCK
-        {   // drain: the last block
+        {   // drain: the last block (in y0, y1)
             const int j0 = (t_end - 1) * MF_TILE_ROWS1 + 3 * MF_JB;
-            x1_close(a0, b0, live0, j0, half, n2, list0, subcap);
-            x1_close(a1, b1, live1, j0, half, n2, list1, subcap);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(b0.M) : "v"(y0[r]), "v"(y0[r + 1]));
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(b1.M) : "v"(y1[r]), "v"(y1[r + 1]));
+            }
+            x1_close(y0, b0, live0, j0, half, n2, list0, subcap);
+            x1_close(y1, b1, live1, j0, half, n2, list1, subcap);
         }
         if (live0) *count0 = b0.cnt;
         if (live1) *count1 = b1.cnt;
