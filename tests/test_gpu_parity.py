@@ -553,6 +553,57 @@ def test_match_non_finite_and_extreme_values(ctx, oracle, algo):
     _match_equal(got, oracle.match(d1, s1, d2, s2, 1000.0))
 
 
+@pytest.mark.parametrize("algo", [api.MATCH_MFMA, api.MATCH_MFMA_BF16, api.MATCH_MFMA_BF16X1])
+def test_match_candidate_overflow_goes_to_exact_scan(ctx, oracle, algo):
+    """list2 ordered so that (almost) every row is a new running minimum for the first queries:
+    their candidate lists overflow (atomic lists and private sub-lists alike) and the exact
+    kernel redoes them; the other queries keep short lists."""
+    rng = np.random.RandomState(5)
+    n1, n2 = 70, 1500
+    base = np.abs(rng.randn(128)).astype(np.float32)
+    base /= np.linalg.norm(base)
+    noise = np.abs(rng.randn(n2, 128)).astype(np.float32)
+    noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+    w = np.linspace(1.0, 0.01, n2, dtype=np.float32)[:, None]      # rows approach `base` steadily
+    d2 = (base[None, :] + w * noise).astype(np.float32)
+    d1 = np.abs(rng.randn(n1, 128)).astype(np.float32)
+    d1 /= np.linalg.norm(d1, axis=1, keepdims=True)
+    d1[:9] = base[None, :] + 1e-3 * d1[:9]
+    s1 = np.full(n1, 800, np.float32)
+    s2 = np.full(n2, 900, np.float32)
+    ctx.set_match_algo(algo)
+    try:
+        got = ctx.match(d1, s1, d2, s2, 1000.0)
+    finally:
+        ctx.set_match_algo(api.MATCH_AUTO)
+    want = oracle.match(d1, s1, d2, s2, 1000.0)
+    _match_equal(got, want)
+    assert (want[0][:9] > n2 - 20).all()          # their nearest rows are the last ones
+
+
+@pytest.mark.parametrize("n1,n2", [(513, 1300), (2100, 5000), (700, 33000), (9000, 40000)])
+def test_match_x1_pieces_and_padding(ctx, oracle, n1, n2):
+    """Shapes that make the x1 kernel cut query blocks into several pieces, leave ragged last
+    query blocks and pad list2 (to whole tiles; to a multiple of 32 tiles from 256 tiles on)."""
+    d1, s1, d2, s2 = synth.descriptor_sets(n1 + n2, n1, n2)
+    ctx.set_match_algo(api.MATCH_MFMA_BF16X1)
+    try:
+        got = ctx.match(d1, s1, d2, s2, 1000.0)
+    finally:
+        ctx.set_match_algo(api.MATCH_AUTO)
+    if n1 * n2 <= 3.0e7:
+        _match_equal(got, oracle.match(d1, s1, d2, s2, 1000.0))
+    else:  # the exact GPU scan is the checker at sizes the CPU oracle would take minutes for
+        ctx.set_match_algo(api.MATCH_EXACT)
+        try:
+            want = ctx.match(d1, s1, d2, s2, 1000.0)
+        finally:
+            ctx.set_match_algo(api.MATCH_AUTO)
+        _match_equal(got, want)
+        k = 300
+        _match_equal([g[:k] for g in got], oracle.match(d1[:k], s1[:k], d2, s2, 1000.0))
+
+
 def test_match_empty_lists(ctx):
     z = np.zeros((0, 128), np.float32)
     e = np.zeros(0, np.float32)
