@@ -730,25 +730,8 @@ __device__ __forceinline__ void load_frag(const uint4 *bf, uint4 (&f)[8])
     for (int s = 0; s < 8; ++s) f[s] = bf[s * 64];
 }
 
-// Close one 32-query chain of a block whose 16 y values (acc) have been folded into b.M: if
-// some lane of the wave may hold a record, run the per-row pass and append the flagged rows.
-__device__ __forceinline__ void x1_close(const f32x16 &acc, BoundX1 &b, bool live, int j0, int half,
-                                         int n2, int *__restrict__ list, int subcap)
-{
-    const bool hit = !(b.M < b.T);
-    if (__any(hit)) {
-        if (__any(b.M == __builtin_inff()))
-            x1_rows<true>(acc, b);
-        else
-            x1_rows<false>(acc, b);
-        const unsigned k = live ? b.mask : 0u;
-        if (__any(k != 0u)) x1_emit(k, b.cnt, list, subcap, j0, half, n2);
-        b.mask = 0;
-    }
-}
-
-// after both chains of a block are closed: Y takes the block maximum, the two half-waves (which
-// hold the two halves of each query's rows) exchange it, and the threshold follows
+// Y takes the block maximum, the two half-waves (which hold the two halves of each query's
+// rows) exchange it, and the threshold follows
 __device__ __forceinline__ void x1_update(BoundX1 &b)
 {
     float y;
@@ -757,6 +740,34 @@ __device__ __forceinline__ void x1_update(BoundX1 &b)
     asm("v_max_f32 %0, %1, %2" : "=v"(b.Y) : "v"(__uint_as_float(sw[0])), "v"(__uint_as_float(sw[1])));
     b.T = b.Y - b.e;
     b.M = -__builtin_inff();
+}
+
+// Close a block whose 16 y values per chain (p0, p1) have been folded into b0.M, b1.M: if some
+// lane of the wave may hold a record, run the per-row pass and append the flagged rows; then
+// bring the bound up to date.  (Refreshing the bound only once per tile was tried: the staler
+// bound costs more in extra candidates than the dozen instructions per block it saves.)
+__device__ __forceinline__ void x1_close(const f32x16 &p0, const f32x16 &p1, BoundX1 &b0, BoundX1 &b1,
+                                         bool live0, bool live1, int j0, int half, int n2,
+                                         int *__restrict__ list0, int *__restrict__ list1, int subcap)
+{
+    const bool hit = !(b0.M < b0.T) || !(b1.M < b1.T);
+    if (__any(hit)) {
+        if (__any(b0.M == __builtin_inff() || b1.M == __builtin_inff())) {
+            x1_rows<true>(p0, b0);
+            x1_rows<true>(p1, b1);
+        } else {
+            x1_rows<false>(p0, b0);
+            x1_rows<false>(p1, b1);
+        }
+        const unsigned k0 = live0 ? b0.mask : 0u, k1 = live1 ? b1.mask : 0u;
+        if (__any((k0 | k1) != 0u)) {
+            x1_emit(k0, b0.cnt, list0, subcap, j0, half, n2);
+            x1_emit(k1, b1.cnt, list1, subcap, j0, half, n2);
+        }
+        b0.mask = b1.mask = 0;
+    }
+    x1_update(b0);
+    x1_update(b1);
 }
 
 // One 32-row block: 16 MFMAs into (x0, x1), both chains starting from c = the block's seeds
@@ -786,12 +797,7 @@ __device__ __forceinline__ void x1_block(const uint4 (&f)[8], const bf16x8 (&qh0
         }
         if (s == 0) c = load_seeds(seeds, seeds_kb, half);
     }
-    if (!FIRST) {
-        x1_close(p0, b0, live0, jprev, half, n2, list0, subcap);
-        x1_close(p1, b1, live1, jprev, half, n2, list1, subcap);
-        x1_update(b0);
-        x1_update(b1);
-    }
+    if (!FIRST) x1_close(p0, p1, b0, b1, live0, live1, jprev, half, n2, list0, list1, subcap);
 #pragma unroll
     for (int s = 4; s < 8; ++s) {
         const bf16x8 fs = __builtin_bit_cast(bf16x8, f[s]);
@@ -937,8 +943,7 @@ __global__ __launch_bounds__(X1_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
                 asm("v_max3_f32 %0, %0, %1, %2" : "+v"(b0.M) : "v"(y0[r]), "v"(y0[r + 1]));
                 asm("v_max3_f32 %0, %0, %1, %2" : "+v"(b1.M) : "v"(y1[r]), "v"(y1[r + 1]));
             }
-            x1_close(y0, b0, live0, j0, half, n2, list0, subcap);
-            x1_close(y1, b1, live1, j0, half, n2, list1, subcap);
+            x1_close(y0, y1, b0, b1, live0, live1, j0, half, n2, list0, list1, subcap);
         }
         if (live0) *count0 = b0.cnt;
         if (live1) *count1 = b1.cnt;
