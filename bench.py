@@ -271,6 +271,24 @@ def main():
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "bytes_per_pixel": 1},
         }
+        # Shi-Tomasi scoring + O(n^2) non-maximum suppression + score ordering of those corners
+        ncorn = int(cnt.item())
+        rng = np.random.RandomState(12)
+        gxy_np = [np.clip(rng.randn(H, W) * 60, 0, 255).astype(np.uint8) for _ in range(2)]  # CV_8U Sobel stand-ins
+        t_gx, t_gy = torch.from_numpy(gxy_np[0]).cuda(), torch.from_numpy(gxy_np[1]).cuda()
+        kern = ctx.gaussian_kernel()
+        s_xy = torch.empty((ncorn, 2), dtype=torch.float32, device="cuda")
+        s_sc = torch.empty(ncorn, dtype=torch.float32, device="cuda")
+        s_ix = torch.empty(ncorn, dtype=torch.int32, device="cuda")
+        s_ct = torch.zeros(1, dtype=torch.int32, device="cuda")
+        xy_in = xy[:ncorn].contiguous()
+        ms = event_time_ms(torch, lambda: ctx.score_cluster_dev(t_gx, t_gy, xy_in, kern, api.ST_THRESH, api.NMS_WINDOW,
+                                                                s_xy, s_sc, s_ix, s_ct), ks, kw)
+        extra["score_nms"] = {
+            "workload": "%d FAST corners of the %dx%d image: Shi-Tomasi score, threshold %.0f, O(n^2) suppression "
+                        "within %d px, ordered by score" % (ncorn, W, H, api.ST_THRESH, api.NMS_WINDOW),
+            "ms": ms, "features_per_s": ncorn / (ms * 1e-3), "survivors": int(s_ct.item()),
+        }
     if not args.no_extra:
         # descriptor matching (BASELINE config 5).  With N > 1 ranks list1's queries are sharded
         # (list2 replicated, no data-path collective): strong scaling of the one 200k x 200k job.
@@ -390,6 +408,18 @@ def main():
                 "sample": "oracle_match, first %d queries x %d (%.1f s, single thread, no per-distance "
                           "heap allocation)" % (nq_cpu, n, dt_m),
                 "matches_gpu_on_sample": same_m}
+            # scoring + NMS: the oracle on the first 15000 corners
+            nsc = min(ncorn, 15000)
+            xy_host = xy_in[:nsc].cpu().numpy()
+            t0 = time.perf_counter()
+            cs = orc.score_and_cluster(gxy_np[0], gxy_np[1], xy_host, kern, api.ST_THRESH, api.NMS_WINDOW)
+            dt_s = time.perf_counter() - t0
+            gs = ctx.score_cluster(gxy_np[0], gxy_np[1], xy_host, kern, api.ST_THRESH, api.NMS_WINDOW)
+            out["extra"]["cpu_score_nms"] = {
+                "value": nsc / dt_s, "unit": "features/s", "cores": 1,
+                "sample": "oracle_score_and_cluster, first %d corners (%.2f s, single thread; O(n^2), so the "
+                          "rate falls with n)" % (nsc, dt_s),
+                "matches_gpu_on_sample": bool(gs[2].tolist() == cs[2].tolist() and gs[1].tobytes() == cs[1].tobytes())}
             # rectification: oracle_rectify on one image of the batch
             t0 = time.perf_counter()
             cr = orc.rectify(src_np[0], np.zeros((rh, rw), np.uint8), Hinv[0].reshape(3, 3))

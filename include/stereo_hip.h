@@ -206,6 +206,34 @@ int stx_fast_detect_u8(stx_ctx *ctx, const uint8_t *img, int w, int h, size_t st
 int stx_fast_detect_u8_dev(stx_ctx *ctx, const uint8_t *d_img, int w, int h, size_t stride,
                            int threshold, float *d_xy, int max_out, int *d_count);
 
+/* ---- Shi-Tomasi scoring + non-maximum suppression (between FAST and the descriptors) ----
+ * Replaces the reference's own arithmetic in ScoreAndClusterFeatures
+ * (stereo/Features.cpp:672-786; decl Features.h:184-188; calls Features.cpp:1184, main.cpp:258):
+ * the scoring loop (:704-746: minimum eigenvalue of the kernel-weighted 3x3 structure matrix,
+ * keep score > score_threshold), the O(n^2) suppression (:752-778: a kept feature is dropped
+ * if a kept feature with a strictly larger score lies within cluster_dist on both axes) and
+ * the sort by score, descending (:783; equal scores keep their input order -- std::sort
+ * leaves that unspecified).  gx, gy are the CV_8U gradient images the reference makes with
+ * OpenCV's GaussianBlur + Sobel (:684-690); they stay with the caller.  kernel3x3 is
+ * CreateGaussianKernel's output (Features.cpp:20-34), row-major as gaussKernel.at<float>(r, c);
+ * stx_gaussian_kernel computes it.  xy: n (x, y) float pairs (Feature::p).  Outputs hold up
+ * to n entries: position, score and index in the input list of every surviving feature;
+ * *count their number.  A feature whose 3x3 window leaves the image (the reference reads out
+ * of bounds there) is dropped.  Host pointers. */
+int stx_score_cluster(stx_ctx *ctx, const uint8_t *gx, const uint8_t *gy, int w, int h, size_t stride,
+                      const float *xy, int n, const float kernel3x3[9], float score_threshold,
+                      float cluster_dist, float *xy_out, float *score_out, int32_t *index_out,
+                      int *count);
+
+/* Device-resident form (kernel3x3 is a host array; d_count a device int); asynchronous. */
+int stx_score_cluster_dev(stx_ctx *ctx, const uint8_t *d_gx, const uint8_t *d_gy, int w, int h,
+                          size_t stride, const float *d_xy, int n, const float kernel3x3[9],
+                          float score_threshold, float cluster_dist, float *d_xy_out,
+                          float *d_score_out, int32_t *d_index_out, int *d_count);
+
+/* CreateGaussianKernel (stereo/Features.cpp:20-34) on the host: out[r * size + c]. */
+int stx_gaussian_kernel(int size, float sigma, float *out);
+
 /* ---- R+D fused on the device ---------------------------------------------
  * main.cpp:362-380 in one call: both images are rectified into zero-initialised
  * destinations of the source size (RectifyImage twice, Stereography.cpp:596-631) and the

@@ -128,3 +128,36 @@ def fast_features(img, threshold=30):
     xy = np.zeros((cap, 2), np.float32)
     n = lib().oracle_fast_features(_p(img), w, h, C.c_size_t(max(w, 1)), int(threshold), _p(xy), cap)
     return xy[:n].copy()
+
+
+def gaussian_kernel(size, sigma):
+    out = np.zeros(size * size, np.float32)
+    lib().oracle_gaussian_kernel(int(size), C.c_float(sigma), _p(out))
+    return out.reshape(size, size)
+
+
+def shi_tomasi_score(gx, gy, x, y, kernel):
+    gx = np.ascontiguousarray(gx, np.uint8)
+    gy = np.ascontiguousarray(gy, np.uint8)
+    k = np.ascontiguousarray(kernel, np.float32).reshape(9)
+    h, w = gx.shape
+    f = lib().oracle_shi_tomasi_score
+    f.restype = C.c_float
+    return float(f(_p(gx), _p(gy), w, h, C.c_size_t(w), C.c_float(x), C.c_float(y), _p(k)))
+
+
+def score_and_cluster(gx, gy, xy, kernel, score_threshold, cluster_dist):
+    gx = np.ascontiguousarray(gx, np.uint8)
+    gy = np.ascontiguousarray(gy, np.uint8)
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    k = np.ascontiguousarray(kernel, np.float32).reshape(9)
+    h, w = gx.shape
+    n = xy.shape[0]
+    oxy = np.zeros((max(n, 1), 2), np.float32)
+    osc = np.zeros(max(n, 1), np.float32)
+    oidx = np.zeros(max(n, 1), np.int32)
+    m = lib().oracle_score_and_cluster(_p(gx), _p(gy), w, h, C.c_size_t(max(w, 1)), _p(xy), n, _p(k),
+                                       C.c_float(score_threshold), C.c_float(cluster_dist), _p(oxy), _p(osc),
+                                       _p(oidx))
+    assert m >= 0
+    return oxy[:m].copy(), osc[:m].copy(), oidx[:m].copy()

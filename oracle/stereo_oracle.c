@@ -490,3 +490,100 @@ long oracle_fast_selfcheck(void)
     }
     return bad;
 }
+
+/* ---------------------------------------------------- scoring + NMS (N3) --- */
+
+/* Features.cpp:20-34 */
+void oracle_gaussian_kernel(int size, float sigma, float *out)
+{
+    for (int y = 0; y < size; ++y) {
+        for (int x = 0; x < size; ++x) {
+            float x_u = x - size / 2.f; /* :26 */
+            float y_u = y - size / 2.f; /* :27 */
+            /* :28; exp of a float argument is the float overload in the reference's C++ */
+            float g = (1.f / (2.f * sigma * sigma * (float)3.14159265358979323846)) *
+                      expf(-1 * (x_u * x_u + y_u * y_u) / (2 * sigma * sigma));
+            out[x * size + y] = g; /* img.at<float>(x, y), :29 */
+        }
+    }
+}
+
+/* Features.cpp:704-740 */
+float oracle_shi_tomasi_score(const uint8_t *gx, const uint8_t *gy, int w, int h, size_t stride,
+                              float px, float py, const float kernel3x3[9])
+{
+    int cy = (int)py, cx = (int)px; /* :718-719 */
+    if (cx < 1 || cy < 1 || cx > w - 2 || cy > h - 2) return NAN;
+    float m00 = 0.f, m01 = 0.f, m10 = 0.f, m11 = 0.f; /* Mat::zeros(2, 2, CV_32F), :708 */
+    for (int n = -1; n <= 1; ++n) {         /* ST_WINDOW / 2 = 1, :714 */
+        for (int m = -1; m <= 1; ++m) {     /* :716 */
+            int i = n + cy, j = m + cx;
+            float wgt = kernel3x3[(n + 1) * 3 + (m + 1)]; /* :720 */
+            int vx = gx[(size_t)i * stride + j], vy = gy[(size_t)i * stride + j];
+            m00 += wgt * (float)(vx * vx); /* :721 */
+            m01 += wgt * (float)(vx * vy); /* :722 */
+            m10 += wgt * (float)(vx * vy); /* :723 */
+            m11 += wgt * (float)(vy * vy); /* :724 */
+        }
+    }
+    float a = 1.f;                                /* :732 */
+    float b = -1 * (m00 + m11);                   /* :733 */
+    float c = m00 * m11 - m10 * m01;              /* :734 */
+    float root = sqrtf(b * b - 4 * a * c);
+    float eigen1 = (-b + root) / 2 * a;           /* :735 */
+    float eigen2 = (-b - root) / 2 * a;           /* :736 */
+    return eigen2 < eigen1 ? eigen2 : eigen1;     /* std::min(eigen1, eigen2), :738 */
+}
+
+/* Features.cpp:704-785 */
+int oracle_score_and_cluster(const uint8_t *gx, const uint8_t *gy, int w, int h, size_t stride,
+                             const float *xy, int n, const float kernel3x3[9],
+                             float score_threshold, float cluster_dist, float *xy_out,
+                             float *score_out, int32_t *index_out)
+{
+    if (n <= 0) return 0;
+    float *score = (float *)malloc(sizeof(float) * (size_t)n);
+    int32_t *good = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    int32_t *kept = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    if (!score || !good || !kept) { free(score); free(good); free(kept); return -1; }
+    int ngood = 0;
+    for (int i = 0; i < n; ++i) {
+        score[i] = oracle_shi_tomasi_score(gx, gy, w, h, stride, xy[2 * i], xy[2 * i + 1], kernel3x3);
+        if (score[i] > score_threshold) good[ngood++] = i; /* :742 */
+    }
+    int nkept = 0;
+    for (int a = 0; a < ngood; ++a) { /* :752-778 */
+        int f = good[a];
+        int is_max = 1;
+        for (int b = 0; b < ngood; ++b) {
+            if (b == a) continue;
+            int f2 = good[b];
+            int xmargin = (int)fabsf(xy[2 * f] - xy[2 * f2]);         /* :762 */
+            int ymargin = (int)fabsf(xy[2 * f + 1] - xy[2 * f2 + 1]); /* :763 */
+            if (xmargin <= cluster_dist && ymargin <= cluster_dist) { /* :764 */
+                if (score[f] < score[f2]) {                           /* :766 */
+                    is_max = 0;
+                    break;
+                }
+            }
+        }
+        if (is_max) kept[nkept++] = f;
+    }
+    /* :783 sort by score descending; insertion by rank keeps equal scores in input order */
+    for (int a = 0; a < nkept; ++a) {
+        int f = kept[a];
+        int rank = 0;
+        for (int b = 0; b < nkept; ++b) {
+            int f2 = kept[b];
+            if (score[f2] > score[f] || (score[f2] == score[f] && b < a)) ++rank;
+        }
+        xy_out[2 * rank] = xy[2 * f];
+        xy_out[2 * rank + 1] = xy[2 * f + 1];
+        score_out[rank] = score[f];
+        index_out[rank] = f;
+    }
+    free(score);
+    free(good);
+    free(kept);
+    return nkept;
+}

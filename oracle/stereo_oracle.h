@@ -112,6 +112,31 @@ int oracle_three_of_four(int i1, int i5, int i9, int i13, int pb, int p_b);
 int oracle_fast_features(const uint8_t *img, int w, int h, size_t stride, int threshold,
                          float *xy_out, int max_out);
 
+/* ---- Shi-Tomasi scoring + non-maximum suppression -------------
+ * CreateGaussianKernel, stereo/Features.cpp:20-34: size x size weights, out[x*size + y]
+ * (the reference writes img.at<float>(x, y); the kernel is symmetric). */
+void oracle_gaussian_kernel(int size, float sigma, float *out);
+
+/* The scoring loop body of ScoreAndClusterFeatures, stereo/Features.cpp:704-740: minimum
+ * eigenvalue of the kernel-weighted structure matrix over the 3x3 window (ST_WINDOW = 3,
+ * Features.h:24) of the CV_8U gradient images around ((int)px, (int)py).  The gradient images
+ * are inputs: the reference makes them with OpenCV's GaussianBlur and Sobel (:684-690),
+ * third-party arithmetic that is not restated here.  A window that leaves the image (the
+ * reference would read out of bounds) returns NaN. */
+float oracle_shi_tomasi_score(const uint8_t *gx, const uint8_t *gy, int w, int h, size_t stride,
+                              float px, float py, const float kernel3x3[9]);
+
+/* ScoreAndClusterFeatures, stereo/Features.cpp:704-785, on given gradient images: score,
+ * keep score > score_threshold (:742), drop every kept feature that has a strictly better
+ * kept feature within cluster_dist on both axes (:752-778), sort by score descending
+ * (:783; std::sort leaves the order of equal scores unspecified: here ties keep the input
+ * order).  xy is n (x, y) pairs; outputs hold up to n entries; index_out = position in the
+ * input list.  Returns the number of surviving features. */
+int oracle_score_and_cluster(const uint8_t *gx, const uint8_t *gy, int w, int h, size_t stride,
+                             const float *xy, int n, const float kernel3x3[9],
+                             float score_threshold, float cluster_dist, float *xy_out,
+                             float *score_out, int32_t *index_out);
+
 #ifdef __cplusplus
 }
 #endif

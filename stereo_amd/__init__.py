@@ -16,6 +16,7 @@ from .api import (
     Feature,
     MatchDescriptors,
     FindFASTFeatures,
+    ScoreAndClusterFeatures,
     RectifyImage,
     ComputeDepthImage,
     MATCH_FAILED,
@@ -28,7 +29,7 @@ from .api import (
 
 __all__ = [
     "StereoHipError", "load_library", "library_path", "Context", "Feature",
-    "MatchDescriptors", "FindFASTFeatures", "RectifyImage", "ComputeDepthImage",
+    "MatchDescriptors", "FindFASTFeatures", "ScoreAndClusterFeatures", "RectifyImage", "ComputeDepthImage",
     "MATCH_FAILED", "MATCH_SCORE", "MATCH_RATIO", "MATCH_ACCEPTED",
     "NN_RATIO", "MAX_DIST_BETWEEN_MATCHES",
 ]

@@ -104,6 +104,42 @@ inline bool FindFASTFeatures(cv::Mat img, std::vector<Feature> &features)
     return true;
 }
 
+// The part of ScoreAndClusterFeatures (Features.h:184-188, Features.cpp:672-786) that is the
+// reference's own arithmetic, on the CV_8U gradient images of :684-690.  The drop-in for the
+// reference's signature is three OpenCV calls in front of it:
+//   GaussianBlur(img, s, Size(ST_WINDOW, ST_WINDOW), 1, 1, BORDER_DEFAULT);
+//   Sobel(s, gx, CV_8U, 1, 0, ST_WINDOW, 1, 0, BORDER_DEFAULT);  Sobel(s, gy, CV_8U, 0, 1, ...);
+//   return ScoreAndClusterFeaturesOnGradients(gx, gy, features, scoreThreshold, distance);
+inline std::vector<Feature> ScoreAndClusterFeaturesOnGradients(const cv::Mat &grad_x, const cv::Mat &grad_y,
+                                                               std::vector<Feature> &features,
+                                                               float scoreThreshold,
+                                                               float distanceForWithinCluster)
+{
+    using namespace stereo_hip_dropin;
+    std::vector<Feature> good;
+    const int n = (int)features.size();
+    if (n == 0 || grad_x.cols != grad_y.cols || grad_x.rows != grad_y.rows || grad_x.step != grad_y.step)
+        return good;
+    float kernel[9];
+    check(stx_gaussian_kernel(3, 1.f, kernel), "stx_gaussian_kernel");  // CreateGaussianKernel, :695-696
+    std::vector<float> xy(2 * (size_t)n), oxy(2 * (size_t)n), score((size_t)n);
+    std::vector<int32_t> index((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        xy[2 * (size_t)i] = features[i].p.x;
+        xy[2 * (size_t)i + 1] = features[i].p.y;
+    }
+    int count = 0;
+    check(stx_score_cluster(context(), grad_x.data, grad_y.data, grad_x.cols, grad_x.rows, (size_t)grad_x.step,
+                            xy.data(), n, kernel, scoreThreshold, distanceForWithinCluster, oxy.data(),
+                            score.data(), index.data(), &count),
+          "stx_score_cluster");
+    for (int i = 0; i < count; ++i) {
+        features[index[i]].score = score[i];  // f is a reference into the caller's list, :706,:739
+        good.push_back(features[index[i]]);
+    }
+    return good;
+}
+
 // Stereography.h:48-51.  H is the forward homography; `rectified` is in/out.
 inline void RectifyImage(const cv::Mat &original, cv::Mat &rectified, const Eigen::Matrix3f &H)
 {

@@ -26,6 +26,9 @@ NN_RATIO = 0.8
 MAX_DIST_BETWEEN_MATCHES = 1000.0
 DESC_LENGTH = 128
 FAST_THRESHOLD = 30  # stereo/Features.h:13
+ST_THRESH = 700.0    # stereo/Features.h:14
+NMS_WINDOW = 2       # stereo/Features.h:16
+ST_WINDOW = 3        # stereo/Features.h:24
 
 MATCH_FAILED, MATCH_SCORE, MATCH_RATIO, MATCH_ACCEPTED = 0, 1, 2, 3
 COST_SAD, COST_SSD = 0, 1
@@ -182,6 +185,48 @@ class Context:
                                                int(img.stride(0)), int(threshold), xy.data_ptr(),
                                                int(xy.shape[0]), count.data_ptr()), "stx_fast_detect_u8_dev")
 
+    # -- scoring + NMS ---------------------------------------------------------
+    def gaussian_kernel(self, size=ST_WINDOW, sigma=1.0):
+        """CreateGaussianKernel, stereo/Features.cpp:20-34 (host)."""
+        out = np.zeros(size * size, np.float32)
+        check(self._lib.stx_gaussian_kernel(int(size), float(sigma), out.ctypes.data_as(C.POINTER(C.c_float))),
+              "stx_gaussian_kernel")
+        return out.reshape(size, size)
+
+    def score_cluster(self, grad_x, grad_y, xy, kernel=None, score_threshold=ST_THRESH,
+                      cluster_dist=NMS_WINDOW):
+        """(xy [m,2], score [m], index [m]) of the surviving features, best score first."""
+        _check_image(grad_x, "grad_x")
+        _check_image(grad_y, "grad_y")
+        if grad_x.shape != grad_y.shape or grad_x.strides != grad_y.strides:
+            raise ValueError("grad_x and grad_y must have the same shape and pitch")
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        n = xy.shape[0]
+        k = np.ascontiguousarray(self.gaussian_kernel() if kernel is None else kernel, np.float32).reshape(9)
+        h, w = grad_x.shape
+        oxy = np.zeros((max(n, 1), 2), np.float32)
+        osc = np.zeros(max(n, 1), np.float32)
+        oidx = np.zeros(max(n, 1), np.int32)
+        cnt = C.c_int(0)
+        check(self._lib.stx_score_cluster(self._h, _ptr(grad_x), _ptr(grad_y), w, h,
+                                          grad_x.strides[0] if h > 1 else max(w, 1), _ptr(xy), n,
+                                          k.ctypes.data_as(C.POINTER(C.c_float)), float(score_threshold),
+                                          float(cluster_dist), _ptr(oxy), _ptr(osc), _ptr(oidx), C.byref(cnt)),
+              "stx_score_cluster")
+        m = cnt.value
+        return oxy[:m], osc[:m], oidx[:m]
+
+    def score_cluster_dev(self, grad_x, grad_y, xy, kernel, score_threshold, cluster_dist, xy_out, score_out,
+                          index_out, count):
+        """Device tensors: grad_* [H,W] uint8, xy [n,2] float32, outputs sized n, count int32[1]."""
+        k = np.ascontiguousarray(kernel, np.float32).reshape(9)
+        check(self._lib.stx_score_cluster_dev(self._h, grad_x.data_ptr(), grad_y.data_ptr(), int(grad_x.shape[1]),
+                                              int(grad_x.shape[0]), int(grad_x.stride(0)), xy.data_ptr(),
+                                              int(xy.shape[0]), k.ctypes.data_as(C.POINTER(C.c_float)),
+                                              float(score_threshold), float(cluster_dist), xy_out.data_ptr(),
+                                              score_out.data_ptr(), index_out.data_ptr(), count.data_ptr()),
+              "stx_score_cluster_dev")
+
     # -- D ------------------------------------------------------------------
     def disparity(self, img0, img1, win=1, max_disp=0, cost_mode=COST_SAD, out_dtype=np.uint8):
         _check_image(img0, "img0")
@@ -315,6 +360,22 @@ def FindFASTFeatures(img, features, ctx=None):
     for x, y in xy:
         features.append(Feature(p=(float(x), float(y))))
     return True
+
+
+def ScoreAndClusterFeatures(grad_x, grad_y, features, scoreThreshold=ST_THRESH,
+                            distanceForWithinCluster=NMS_WINDOW, ctx=None):
+    """ScoreAndClusterFeatures, stereo/Features.cpp:672-786, on the CV_8U gradient images the
+    reference makes with OpenCV's GaussianBlur + Sobel (:684-690; they stay with the caller).
+    Returns the surviving features, best score first, as copies with `score` set."""
+    ctx = ctx or default_context()
+    xy = np.array([f.p for f in features], np.float32).reshape(-1, 2)
+    _, score, index = ctx.score_cluster(grad_x, grad_y, xy, None, scoreThreshold, distanceForWithinCluster)
+    out = []
+    for s, i in zip(score, index):
+        f = copy.deepcopy(features[int(i)])
+        f.score = float(s)
+        out.append(f)
+    return out
 
 
 def RectifyImage(original, rectified, H, ctx=None):

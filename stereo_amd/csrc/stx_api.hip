@@ -503,3 +503,83 @@ extern "C" int stx_fast_detect_u8(stx_ctx *ctx, const uint8_t *img, int w, int h
     }
     return STX_OK;
 }
+
+// ---------------------------------------------------------- scoring + NMS --
+
+extern "C" int stx_gaussian_kernel(int size, float sigma, float *out)
+{
+    if (size <= 0 || !out) return STX_ERR_INVALID_ARG;
+    // Features.cpp:22-31 (the reference writes img.at<float>(x, y); the kernel is symmetric)
+    for (int y = 0; y < size; ++y)
+        for (int x = 0; x < size; ++x) {
+            const float x_u = x - size / 2.f;
+            const float y_u = y - size / 2.f;
+            const float g = (1.f / (2.f * sigma * sigma * (float)3.14159265358979323846)) *
+                            expf(-1 * (x_u * x_u + y_u * y_u) / (2 * sigma * sigma));
+            out[x * size + y] = g;
+        }
+    return STX_OK;
+}
+
+extern "C" int stx_score_cluster_dev(stx_ctx *ctx, const uint8_t *d_gx, const uint8_t *d_gy, int w, int h,
+                                     size_t stride, const float *d_xy, int n, const float kernel3x3[9],
+                                     float score_threshold, float cluster_dist, float *d_xy_out,
+                                     float *d_score_out, int32_t *d_index_out, int *d_count)
+{
+    if (!ctx || !kernel3x3 || !d_count || n < 0) return STX_ERR_INVALID_ARG;
+    if (n > 0 && (!d_xy || !d_xy_out || !d_score_out || !d_index_out)) return STX_ERR_INVALID_ARG;
+    int rc = check_image(d_gx, w, h, stride);
+    if (rc) return rc;
+    rc = check_image(d_gy, w, h, stride);
+    if (rc) return rc;
+    STX_HIP(hipSetDevice(ctx->device));
+    return stx_launch_score_cluster(ctx, d_gx, d_gy, w, h, stride, d_xy, n, kernel3x3, score_threshold,
+                                    cluster_dist, d_xy_out, d_score_out, d_index_out, d_count);
+}
+
+extern "C" int stx_score_cluster(stx_ctx *ctx, const uint8_t *gx, const uint8_t *gy, int w, int h,
+                                 size_t stride, const float *xy, int n, const float kernel3x3[9],
+                                 float score_threshold, float cluster_dist, float *xy_out, float *score_out,
+                                 int32_t *index_out, int *count)
+{
+    if (!ctx || !kernel3x3 || !count || n < 0) return STX_ERR_INVALID_ARG;
+    if (n > 0 && (!xy || !xy_out || !score_out || !index_out)) return STX_ERR_INVALID_ARG;
+    int rc = check_image(gx, w, h, stride);
+    if (rc) return rc;
+    rc = check_image(gy, w, h, stride);
+    if (rc) return rc;
+    *count = 0;
+    if (n == 0) return STX_OK;
+    STX_HIP(hipSetDevice(ctx->device));
+    int err;
+    hipStream_t s = ctx->stream;
+    const size_t p = (size_t)(w > 0 ? w : 1), img = (p * (size_t)(h > 0 ? h : 1) + 15) & ~(size_t)15;
+    // [gx][gy][xy n*2][xy_out n*2][score_out n][index_out n][count]
+    const size_t bytes = 2 * img + sizeof(float) * (size_t)n * 6 + 16;
+    uint8_t *base = (uint8_t *)stx_workspace(ctx, STX_SLOT_SCORE_IO, bytes, &err);
+    if (!base) return err;
+    uint8_t *dgx = base, *dgy = base + img;
+    float *dxy = reinterpret_cast<float *>(base + 2 * img);
+    float *dxy_out = dxy + 2 * (size_t)n;
+    float *dscore = dxy_out + 2 * (size_t)n;
+    int32_t *dindex = reinterpret_cast<int32_t *>(dscore + n);
+    int *dcount = dindex + n;
+    if (w > 0 && h > 0) {
+        STX_HIP(copy_image_h2d(dgx, p, gx, stride, (size_t)w, (size_t)h, s));
+        STX_HIP(copy_image_h2d(dgy, p, gy, stride, (size_t)w, (size_t)h, s));
+    }
+    STX_HIP(hipMemcpyAsync(dxy, xy, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, s));
+    rc = stx_launch_score_cluster(ctx, dgx, dgy, w, h, p, dxy, n, kernel3x3, score_threshold, cluster_dist,
+                                  dxy_out, dscore, dindex, dcount);
+    if (rc) return rc;
+    STX_HIP(hipMemcpyAsync(count, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
+    STX_HIP(hipStreamSynchronize(s));
+    const size_t m = (size_t)*count;
+    if (m > 0) {
+        STX_HIP(hipMemcpyAsync(xy_out, dxy_out, sizeof(float) * 2 * m, hipMemcpyDeviceToHost, s));
+        STX_HIP(hipMemcpyAsync(score_out, dscore, sizeof(float) * m, hipMemcpyDeviceToHost, s));
+        STX_HIP(hipMemcpyAsync(index_out, dindex, sizeof(int32_t) * m, hipMemcpyDeviceToHost, s));
+        STX_HIP(hipStreamSynchronize(s));
+    }
+    return STX_OK;
+}

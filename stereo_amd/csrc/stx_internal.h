@@ -22,6 +22,8 @@ enum stx_slot {
     STX_SLOT_M_CAND,     // match: candidate lists + counters
     STX_SLOT_M_FALLBACK, // match: overflow query list
     STX_SLOT_FAST,       // FAST: corner bit words + prefix sums
+    STX_SLOT_SCORE,      // scoring + NMS: scores, index lists, flags, counts
+    STX_SLOT_SCORE_IO,   // host-API staging of the scoring call: gradient images, features, outputs
     STX_SLOT_COUNT
 };
 
@@ -64,3 +66,8 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
 
 int stx_launch_fast(stx_ctx *ctx, const uint8_t *d_img, int w, int h, size_t stride, int threshold,
                     float *d_xy, int max_out, int *d_count);
+
+int stx_launch_score_cluster(stx_ctx *ctx, const uint8_t *d_gx, const uint8_t *d_gy, int w, int h,
+                             size_t stride, const float *d_xy, int n, const float kernel3x3[9],
+                             float score_threshold, float cluster_dist, float *d_xy_out,
+                             float *d_score_out, int32_t *d_index_out, int *d_count);

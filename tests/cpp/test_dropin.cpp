@@ -124,6 +124,32 @@ int main()
         if (n < 10) ++fails;
         std::printf("FAST fails so far: %d (corners %d)\n", fails, n);
     }
+    {   // ScoreAndClusterFeatures on gradient images
+        const int w = 160, h = 90, n = 900;
+        cv::Mat gx = cv::Mat::zeros(cv::Size(w, h), CV_8U), gy = cv::Mat::zeros(cv::Size(w, h), CV_8U);
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                gx.at<uint8_t>(y, x) = (uint8_t)(rnd() % 3 ? rnd() % 200 : 0);
+                gy.at<uint8_t>(y, x) = (uint8_t)(rnd() % 3 ? rnd() % 200 : 0);
+            }
+        std::vector<Feature> feats(n);
+        std::vector<float> xy(2 * n);
+        for (int i = 0; i < n; ++i) {
+            feats[i].p.x = xy[2 * i] = (float)(rnd() % w);
+            feats[i].p.y = xy[2 * i + 1] = (float)(rnd() % h);
+        }
+        std::vector<Feature> good = ScoreAndClusterFeaturesOnGradients(gx, gy, feats, 700.f, 2.f);
+        float kernel[9];
+        oracle_gaussian_kernel(3, 1.f, kernel);
+        std::vector<float> oxy(2 * n), osc(n);
+        std::vector<int32_t> oidx(n);
+        const int m = oracle_score_and_cluster(gx.data, gy.data, w, h, gx.step, xy.data(), n, kernel, 700.f, 2.f,
+                                               oxy.data(), osc.data(), oidx.data());
+        if ((int)good.size() != m || m < 10) ++fails;
+        for (int i = 0; i < m && i < (int)good.size(); ++i)
+            if (good[i].p.x != oxy[2 * i] || good[i].p.y != oxy[2 * i + 1] || good[i].score != osc[i]) ++fails;
+        std::printf("score+NMS fails so far: %d (survivors %d of %d)\n", fails, m, n);
+    }
     std::printf(fails ? "DROPIN FAIL\n" : "DROPIN OK\n");
     return fails ? 1 : 0;
 }

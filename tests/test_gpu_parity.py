@@ -720,3 +720,101 @@ def test_fast_full_size(ctx, oracle):
     got, n = ctx.fast_detect(img, 30)
     want = oracle.fast_features(img, 30)
     assert n == len(want) > 1000 and got.tobytes() == want.tobytes()
+
+
+# ------------------------------------------- scoring + NMS (N3, second part) ------
+
+def _grad_images(seed, h, w):
+    """Stand-ins for the CV_8U GaussianBlur + Sobel outputs (Features.cpp:684-690): Sobel with
+    ddepth CV_8U saturates negatives to 0, so about half of the gradient pixels are 0."""
+    rng = np.random.RandomState(seed)
+    gx = np.clip(rng.randn(h, w) * 60, 0, 255).astype(np.uint8)
+    gy = np.clip(rng.randn(h, w) * 60, 0, 255).astype(np.uint8)
+    return gx, gy
+
+
+def _score_equal(got, want):
+    assert got[2].tolist() == want[2].tolist()
+    assert got[0].tobytes() == want[0].tobytes()
+    assert got[1].tobytes() == want[1].tobytes()
+
+
+@pytest.mark.parametrize("h,w,n", [(40, 50, 1), (40, 50, 300), (120, 333, 5000), (500, 741, 20000)])
+def test_score_cluster_matches_oracle(ctx, oracle, h, w, n):
+    gx, gy = _grad_images(h + n, h, w)
+    rng = np.random.RandomState(n)
+    xy = np.stack([rng.randint(0, w, n), rng.randint(0, h, n)], 1).astype(np.float32)
+    xy[: n // 3] += rng.rand(n // 3, 2).astype(np.float32) * 0.9   # fractional positions truncate
+    k = ctx.gaussian_kernel()
+    assert k.tobytes() == oracle.gaussian_kernel(3, 1.0).tobytes()
+    for thr, dist in [(700.0, 2.0), (0.0, 2.0), (3000.0, 5.0), (1e9, 2.0)]:
+        got = ctx.score_cluster(gx, gy, xy, k, thr, dist)
+        want = oracle.score_and_cluster(gx, gy, xy, k, thr, dist)
+        _score_equal(got, want)
+    assert len(oracle.score_and_cluster(gx, gy, xy, k, 1e9, 2.0)[2]) == 0
+
+
+def test_score_cluster_edge_cases(ctx, oracle):
+    gx, gy = _grad_images(3, 30, 30)
+    k = ctx.gaussian_kernel()
+    # no features
+    got = ctx.score_cluster(gx, gy, np.zeros((0, 2), np.float32), k, 700.0, 2.0)
+    assert len(got[0]) == 0 and len(got[2]) == 0
+    # border features (window leaves the image), duplicates of one position (equal scores keep
+    # their input order), flat regions (rank-deficient matrix, negative discriminant by rounding)
+    gx[10:20, 10:20] = 7
+    gy[10:20, 10:20] = 7
+    xy = np.array([(0, 5), (29, 5), (5, 0), (5, 29), (15, 15), (8, 8), (8, 8), (8, 8), (9, 8), (14.5, 14.5),
+                   (1, 1), (28, 28)], np.float32)
+    for thr in (700.0, -1.0):
+        _score_equal(ctx.score_cluster(gx, gy, xy, k, thr, 2.0), oracle.score_and_cluster(gx, gy, xy, k, thr, 2.0))
+    # pitched gradient images
+    big_x = np.zeros((30, 64), np.uint8); big_y = np.zeros((30, 64), np.uint8)
+    big_x[:, 7:37] = gx; big_y[:, 7:37] = gy
+    _score_equal(ctx.score_cluster(big_x[:, 7:37], big_y[:, 7:37], xy, k, 700.0, 2.0),
+                 oracle.score_and_cluster(gx, gy, xy, k, 700.0, 2.0))
+
+
+def test_score_and_cluster_features_reference_signature(ctx, oracle):
+    """FindFASTFeatures -> ScoreAndClusterFeatures (Features.cpp:1179-1184) on the GPU."""
+    img = synth.texture(77, 120, 200)
+    feats = []
+    api.FindFASTFeatures(img, feats, ctx=ctx)
+    gx, gy = _grad_images(5, 120, 200)
+    out = api.ScoreAndClusterFeatures(gx, gy, feats, api.ST_THRESH, api.NMS_WINDOW, ctx=ctx)
+    xy = np.array([f.p for f in feats], np.float32)
+    wxy, wsc, _ = oracle.score_and_cluster(gx, gy, xy, oracle.gaussian_kernel(3, 1.0), 700.0, 2.0)
+    assert len(out) == len(wsc) and len(out) > 10
+    assert [f.p for f in out] == [tuple(map(float, p)) for p in wxy]
+    assert np.array([f.score for f in out], np.float32).tobytes() == wsc.tobytes()
+
+
+def test_score_cluster_dev_full_size(ctx, oracle):
+    import torch
+    h, w = 1988, 2880
+    img = synth.texture(2024, h, w)
+    gx, gy = _grad_images(9, h, w)
+    xy_all, cnt = ctx.fast_detect(img)
+    n = min(cnt, 60000)
+    xy = np.ascontiguousarray(xy_all[:n])
+    k = ctx.gaussian_kernel()
+    t = [torch.from_numpy(a).cuda() for a in (gx, gy, xy)]
+    oxy = torch.empty((n, 2), dtype=torch.float32, device="cuda")
+    osc = torch.empty(n, dtype=torch.float32, device="cuda")
+    oidx = torch.empty(n, dtype=torch.int32, device="cuda")
+    ocnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.score_cluster_dev(t[0], t[1], t[2], k, 700.0, 2.0, oxy, osc, oidx, ocnt)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_stream(0)
+    m = int(ocnt.item())
+    sc = osc[:m].cpu().numpy()
+    idx = oidx[:m].cpu().numpy()
+    # properties at full size: sorted, indices distinct, survivors are local maxima
+    assert m > 1000 and (np.diff(sc) <= 0).all() and len(set(idx.tolist())) == m
+    # and the oracle on the first 6000 input features
+    sub = 6000
+    _score_equal(ctx.score_cluster(gx, gy, xy[:sub], k, 700.0, 2.0),
+                 oracle.score_and_cluster(gx, gy, xy[:sub], k, 700.0, 2.0))

@@ -276,3 +276,112 @@ def test_fast_features_hand_image(oracle):
     assert (8, 8) not in got
     # flat image: nothing
     assert len(oracle.fast_features(np.full((20, 20), 90, np.uint8), 30)) == 0
+
+
+# ------------------------------------------------- scoring + NMS (N3) ------
+
+def _kernel_np():
+    """CreateGaussianKernel (Features.cpp:20-34) restated a second time, in numpy float32."""
+    f = np.float32
+    k = np.zeros((3, 3), np.float32)
+    for y in range(3):
+        for x in range(3):
+            xu, yu = f(x) - f(3) / f(2), f(y) - f(3) / f(2)
+            g = (f(1) / (f(2) * f(1) * f(1) * f(np.pi))) * f(np.exp(f(-1) * (xu * xu + yu * yu) / (f(2) * f(1) * f(1))))
+            k[x, y] = g
+    return k
+
+
+def _score_np(gx, gy, x, y, k):
+    """Features.cpp:704-738 restated a second time, every operation rounded to float32."""
+    f = np.float32
+    m00 = m01 = m10 = m11 = f(0)
+    cy, cx = int(y), int(x)
+    for n in (-1, 0, 1):
+        for m in (-1, 0, 1):
+            w = k[n + 1, m + 1]
+            vx, vy = int(gx[cy + n, cx + m]), int(gy[cy + n, cx + m])
+            m00 = f(m00 + f(w * f(vx * vx)))
+            m01 = f(m01 + f(w * f(vx * vy)))
+            m10 = f(m10 + f(w * f(vx * vy)))
+            m11 = f(m11 + f(w * f(vy * vy)))
+    b = f(f(-1) * f(m00 + m11))
+    c = f(f(m00 * m11) - f(m10 * m01))
+    with np.errstate(invalid="ignore"):
+        root = f(np.sqrt(f(f(b * b) - f(f(4) * c))))
+    e1 = f(f(-b + root) / f(2))
+    e2 = f(f(-b - root) / f(2))
+    return e2 if e2 < e1 else e1
+
+
+def test_gaussian_kernel_matches_second_restatement(oracle):
+    k = oracle.gaussian_kernel(3, 1.0)
+    k2 = _kernel_np()
+    # libm expf vs numpy exp may differ in the last place; the weights are an input of the
+    # scoring functions, so only their values (not bits) are pinned here
+    assert np.allclose(k, k2, rtol=1e-6, atol=0)
+    # the reference centres the kernel at size/2.f = 1.5, i.e. between taps 1 and 2 (:26-27)
+    assert k[1, 1] == k[2, 2] == k[1, 2] and k[0, 0] < k[0, 1] < k[1, 1]
+
+
+def test_shi_tomasi_hand_cases(oracle):
+    k = oracle.gaussian_kernel(3, 1.0)
+    gx = np.full((9, 9), 10, np.uint8)
+    gy = np.zeros((9, 9), np.uint8)
+    # gy == 0: M = [[s, 0], [0, 0]] -> eigenvalues s and 0 -> min 0 (:733-738)
+    assert oracle.shi_tomasi_score(gx, gy, 4, 4, k) == 0.0
+    # gx == gy: rank-one M -> min eigenvalue 0
+    assert oracle.shi_tomasi_score(gx, gx, 4, 4, k) == 0.0
+    # one x-gradient tap and one y-gradient tap: M diagonal -> min(w_a gx^2, w_b gy^2) up to rounding
+    gx = np.zeros((9, 9), np.uint8); gy = np.zeros((9, 9), np.uint8)
+    gx[4, 4] = 200; gy[5, 5] = 100
+    want = min(k[1, 1] * 200 * 200, k[2, 2] * 100 * 100)
+    got = oracle.shi_tomasi_score(gx, gy, 4.9, 4.2, k)   # (int) truncation of the position (:718-719)
+    assert abs(got - want) <= 1e-3 * want
+    # window leaving the image: dropped (the reference would read out of bounds)
+    assert np.isnan(oracle.shi_tomasi_score(gx, gy, 0, 4, k))
+    assert np.isnan(oracle.shi_tomasi_score(gx, gy, 4, 8, k))
+
+
+def test_shi_tomasi_matches_second_restatement_bit_for_bit(oracle):
+    rng = np.random.RandomState(11)
+    k = oracle.gaussian_kernel(3, 1.0)
+    gx = rng.randint(0, 256, (30, 40)).astype(np.uint8)
+    gy = rng.randint(0, 256, (30, 40)).astype(np.uint8)
+    gx[10:20, 10:20] = 0
+    gy[10:20, 10:20] = rng.randint(0, 3, (10, 10))
+    for _ in range(300):
+        x, y = rng.randint(1, 39), rng.randint(1, 29)
+        a = np.float32(oracle.shi_tomasi_score(gx, gy, float(x), float(y), k))
+        b = _score_np(gx, gy, x, y, k)
+        assert a.tobytes() == np.float32(b).tobytes() or (np.isnan(a) and np.isnan(b))
+
+
+def test_score_and_cluster_hand_case(oracle):
+    # scores are planted through single-tap gradients: score = min(w11 gx^2, w22 gy^2)
+    k = oracle.gaussian_kernel(3, 1.0)
+    gx = np.zeros((20, 40), np.uint8); gy = np.zeros((20, 40), np.uint8)
+
+    def plant(x, y, v):
+        gx[y, x] = v
+        gy[y + 1, x + 1] = v
+
+    pts = [(10, 5, 100), (12, 5, 90), (14, 5, 110),   # a-b and b-c within 2, a-c not (:762-764)
+           (30, 10, 120), (30, 13, 120),              # 3 apart on y: both stay
+           (20, 15, 120),                             # same score as the two above: ties keep input order
+           (5, 15, 50)]                               # below the threshold (:742)
+    for x, y, v in pts:
+        plant(x, y, v)
+    xy = np.array([(x, y) for x, y, _ in pts], np.float32)
+    thr = float(k[1, 1]) * 60 * 60
+    oxy, osc, oidx = oracle.score_and_cluster(gx, gy, xy, k, thr, 2.0)
+    # b (index 1) loses to a; the 50 is below the threshold; order: 120s in input order, 110, 100
+    assert oidx.tolist() == [3, 4, 5, 2, 0]
+    assert (np.diff(osc) <= 0).all()
+    assert oxy.tolist() == [[30, 10], [30, 13], [20, 15], [14, 5], [10, 5]]
+    # a fractional offset of 2.9 truncates to 2: still inside the window (:762)
+    xy2 = np.array([(10, 5), (12.9, 5.2)], np.float32)
+    gx[:] = 0; gy[:] = 0
+    plant(10, 5, 100); plant(12, 5, 150)
+    _, _, idx2 = oracle.score_and_cluster(gx, gy, xy2, k, thr, 2.0)
+    assert idx2.tolist() == [1]
