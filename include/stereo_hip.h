@@ -231,6 +231,18 @@ int stx_score_cluster_dev(stx_ctx *ctx, const uint8_t *d_gx, const uint8_t *d_gy
                           float score_threshold, float cluster_dist, float *d_xy_out,
                           float *d_score_out, int32_t *d_index_out, int *d_count);
 
+/* Replaces ClusterFeatures (stereo/Features.cpp:48-80; decl Features.h:176-178; call :375):
+ * non-maximum suppression over features that already carry scores -- feature a is dropped if a
+ * feature with a strictly larger score lies within `window` on both axes ((int)abs margins,
+ * <= test, :61-65).  index_out receives the input positions of the survivors, in input order;
+ * *count their number.  Host pointers. */
+int stx_cluster_features(stx_ctx *ctx, const float *xy, const float *score, int n, int window,
+                         int32_t *index_out, int *count);
+
+/* Device-resident form (d_count a device int); asynchronous. */
+int stx_cluster_features_dev(stx_ctx *ctx, const float *d_xy, const float *d_score, int n, int window,
+                             int32_t *d_index_out, int *d_count);
+
 /* CreateGaussianKernel (stereo/Features.cpp:20-34) on the host: out[r * size + c]. */
 int stx_gaussian_kernel(int size, float sigma, float *out);
 

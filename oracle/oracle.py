@@ -161,3 +161,12 @@ def score_and_cluster(gx, gy, xy, kernel, score_threshold, cluster_dist):
                                        _p(oidx))
     assert m >= 0
     return oxy[:m].copy(), osc[:m].copy(), oidx[:m].copy()
+
+
+def cluster_features(xy, score, window):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    score = np.ascontiguousarray(score, np.float32).reshape(-1)
+    n = xy.shape[0]
+    idx = np.zeros(max(n, 1), np.int32)
+    m = lib().oracle_cluster_features(_p(xy), _p(score), n, int(window), _p(idx))
+    return idx[:m].copy()

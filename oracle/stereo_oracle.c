@@ -587,3 +587,25 @@ int oracle_score_and_cluster(const uint8_t *gx, const uint8_t *gy, int w, int h,
     free(kept);
     return nkept;
 }
+
+/* Features.cpp:48-80 */
+int oracle_cluster_features(const float *xy, const float *score, int n, int window, int32_t *index_out)
+{
+    int kept = 0;
+    for (int a = 0; a < n; ++a) {
+        int is_max = 1;
+        for (int b = 0; b < n; ++b) {
+            if (b == a) continue;                                     /* :57 */
+            int xmargin = (int)fabsf(xy[2 * a] - xy[2 * b]);         /* :61 */
+            int ymargin = (int)fabsf(xy[2 * a + 1] - xy[2 * b + 1]); /* :62 */
+            if (xmargin <= window && ymargin <= window) {            /* :63 */
+                if (score[a] < score[b]) {                           /* :65 */
+                    is_max = 0;
+                    break;
+                }
+            }
+        }
+        if (is_max) index_out[kept++] = a;
+    }
+    return kept;
+}

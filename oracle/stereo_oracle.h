@@ -126,6 +126,10 @@ void oracle_gaussian_kernel(int size, float sigma, float *out);
 float oracle_shi_tomasi_score(const uint8_t *gx, const uint8_t *gy, int w, int h, size_t stride,
                               float px, float py, const float kernel3x3[9]);
 
+/* ClusterFeatures, stereo/Features.cpp:48-80: index_out receives the input positions of the
+ * features that no strictly better feature has inside its window; returns their number. */
+int oracle_cluster_features(const float *xy, const float *score, int n, int window, int32_t *index_out);
+
 /* ScoreAndClusterFeatures, stereo/Features.cpp:704-785, on given gradient images: score,
  * keep score > score_threshold (:742), drop every kept feature that has a strictly better
  * kept feature within cluster_dist on both axes (:752-778), sort by score descending

@@ -17,6 +17,7 @@ from .api import (
     MatchDescriptors,
     FindFASTFeatures,
     ScoreAndClusterFeatures,
+    ClusterFeatures,
     RectifyImage,
     ComputeDepthImage,
     MATCH_FAILED,
@@ -29,7 +30,7 @@ from .api import (
 
 __all__ = [
     "StereoHipError", "load_library", "library_path", "Context", "Feature",
-    "MatchDescriptors", "FindFASTFeatures", "ScoreAndClusterFeatures", "RectifyImage", "ComputeDepthImage",
+    "MatchDescriptors", "FindFASTFeatures", "ScoreAndClusterFeatures", "ClusterFeatures", "RectifyImage", "ComputeDepthImage",
     "MATCH_FAILED", "MATCH_SCORE", "MATCH_RATIO", "MATCH_ACCEPTED",
     "NN_RATIO", "MAX_DIST_BETWEEN_MATCHES",
 ]

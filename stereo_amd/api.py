@@ -216,6 +216,19 @@ class Context:
         m = cnt.value
         return oxy[:m], osc[:m], oidx[:m]
 
+    def cluster_features(self, xy, score, window):
+        """Input positions of the features that survive ClusterFeatures, in input order."""
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        score = np.ascontiguousarray(score, np.float32).reshape(-1)
+        n = xy.shape[0]
+        if score.shape[0] != n:
+            raise ValueError("xy and score must have the same length")
+        idx = np.zeros(max(n, 1), np.int32)
+        cnt = C.c_int(0)
+        check(self._lib.stx_cluster_features(self._h, _ptr(xy), _ptr(score), n, int(window), _ptr(idx),
+                                             C.byref(cnt)), "stx_cluster_features")
+        return idx[:cnt.value]
+
     def score_cluster_dev(self, grad_x, grad_y, xy, kernel, score_threshold, cluster_dist, xy_out, score_out,
                           index_out, count):
         """Device tensors: grad_* [H,W] uint8, xy [n,2] float32, outputs sized n, count int32[1]."""
@@ -360,6 +373,15 @@ def FindFASTFeatures(img, features, ctx=None):
     for x, y in xy:
         features.append(Feature(p=(float(x), float(y))))
     return True
+
+
+def ClusterFeatures(features, windowSize, ctx=None):
+    """ClusterFeatures, stereo/Features.cpp:48-80: the features that are the strongest inside
+    their window, in input order."""
+    ctx = ctx or default_context()
+    xy = np.array([f.p for f in features], np.float32).reshape(-1, 2)
+    score = np.array([f.score for f in features], np.float32)
+    return [features[int(i)] for i in ctx.cluster_features(xy, score, windowSize)]
 
 
 def ScoreAndClusterFeatures(grad_x, grad_y, features, scoreThreshold=ST_THRESH,

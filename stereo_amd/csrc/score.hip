@@ -133,17 +133,18 @@ __global__ __launch_bounds__(SC_THREADS) void compact_kernel(
 // Features.cpp:752-778 over the kept features good[0 .. *ngood): feature a survives unless a
 // kept feature b != a lies within `dist` on both axes and has a strictly larger score.
 __global__ __launch_bounds__(SC_THREADS) void nms_kernel(
-    const float2 *__restrict__ xy, const float *__restrict__ score, const int *__restrict__ good,
+    const float2 *__restrict__ xy, const float *__restrict__ score, const int *__restrict__ good, int n,
     const int *__restrict__ ngood, float dist, uint8_t *__restrict__ keep, int *__restrict__ tile_counts)
 {
+    // good == null: the kept list is the whole input list (ClusterFeatures); ngood == null: n
     __shared__ float sx[SC_THREADS], sy[SC_THREADS], ss[SC_THREADS];
-    const int ng = *ngood;
+    const int ng = ngood ? *ngood : n;
     const int tiles = (ng + SC_THREADS - 1) / SC_THREADS;
     if ((int)blockIdx.x >= tiles) return;
     const int a = blockIdx.x * SC_THREADS + threadIdx.x;
     float ax = 0.f, ay = 0.f, as = 0.f;
     if (a < ng) {
-        const int f = good[a];
+        const int f = good ? good[a] : a;
         const float2 p = xy[f];
         ax = p.x; ay = p.y; as = score[f];
     }
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(SC_THREADS) void nms_kernel(
     for (int t0 = 0; t0 < ng; t0 += SC_THREADS) {
         const int b = t0 + threadIdx.x;
         if (b < ng) {
-            const int f2 = good[b];
+            const int f2 = good ? good[b] : b;
             const float2 p = xy[f2];
             sx[threadIdx.x] = p.x; sy[threadIdx.x] = p.y; ss[threadIdx.x] = score[f2];
         }
@@ -231,11 +232,30 @@ int stx_launch_score_cluster(stx_ctx *ctx, const uint8_t *d_gx, const uint8_t *d
                        score_threshold, score, keep, tile_counts);
     hipLaunchKernelGGL(compact_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, keep, tile_counts,
                        (const int *)nullptr, n, (const int *)nullptr, good, counts);
-    hipLaunchKernelGGL(nms_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, xy, score, good, counts, cluster_dist,
+    hipLaunchKernelGGL(nms_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, xy, score, good, n, counts, cluster_dist,
                        keep, tile_counts);
     hipLaunchKernelGGL(compact_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, keep, tile_counts, good, n, counts,
                        kept, d_count);
     hipLaunchKernelGGL(rank_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, xy, score, kept, d_count,
                        reinterpret_cast<float2 *>(d_xy_out), d_score_out, d_index_out);
+    return (int)hipGetLastError();
+}
+
+// ClusterFeatures (stereo/Features.cpp:48-80): the same suppression over a list that already
+// carries scores; survivors keep their input order.
+int stx_launch_cluster(stx_ctx *ctx, const float *d_xy, const float *d_score, int n, float window,
+                       int32_t *d_index_out, int *d_count)
+{
+    hipStream_t st = ctx->stream;
+    if (n <= 0) return (int)hipMemsetAsync(d_count, 0, sizeof(int), st);
+    const int tiles = (n + SC_THREADS - 1) / SC_THREADS;
+    int err;
+    int *tile_counts = (int *)stx_workspace(ctx, STX_SLOT_SCORE, sizeof(int) * (size_t)tiles + (size_t)n, &err);
+    if (!tile_counts) return err;
+    uint8_t *keep = reinterpret_cast<uint8_t *>(tile_counts + tiles);
+    hipLaunchKernelGGL(nms_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, reinterpret_cast<const float2 *>(d_xy),
+                       d_score, (const int *)nullptr, n, (const int *)nullptr, window, keep, tile_counts);
+    hipLaunchKernelGGL(compact_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, keep, tile_counts,
+                       (const int *)nullptr, n, (const int *)nullptr, d_index_out, d_count);
     return (int)hipGetLastError();
 }

@@ -583,3 +583,41 @@ extern "C" int stx_score_cluster(stx_ctx *ctx, const uint8_t *gx, const uint8_t 
     }
     return STX_OK;
 }
+
+extern "C" int stx_cluster_features_dev(stx_ctx *ctx, const float *d_xy, const float *d_score, int n, int window,
+                                        int32_t *d_index_out, int *d_count)
+{
+    if (!ctx || !d_count || n < 0) return STX_ERR_INVALID_ARG;
+    if (n > 0 && (!d_xy || !d_score || !d_index_out)) return STX_ERR_INVALID_ARG;
+    STX_HIP(hipSetDevice(ctx->device));
+    return stx_launch_cluster(ctx, d_xy, d_score, n, (float)window, d_index_out, d_count);
+}
+
+extern "C" int stx_cluster_features(stx_ctx *ctx, const float *xy, const float *score, int n, int window,
+                                    int32_t *index_out, int *count)
+{
+    if (!ctx || !count || n < 0) return STX_ERR_INVALID_ARG;
+    if (n > 0 && (!xy || !score || !index_out)) return STX_ERR_INVALID_ARG;
+    *count = 0;
+    if (n == 0) return STX_OK;
+    STX_HIP(hipSetDevice(ctx->device));
+    int err;
+    hipStream_t s = ctx->stream;
+    // [xy n*2][score n][index n][count]
+    float *dxy = (float *)stx_workspace(ctx, STX_SLOT_SCORE_IO, sizeof(float) * (size_t)n * 4 + 16, &err);
+    if (!dxy) return err;
+    float *dscore = dxy + 2 * (size_t)n;
+    int32_t *dindex = reinterpret_cast<int32_t *>(dscore + n);
+    int *dcount = dindex + n;
+    STX_HIP(hipMemcpyAsync(dxy, xy, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, s));
+    STX_HIP(hipMemcpyAsync(dscore, score, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, s));
+    int rc = stx_launch_cluster(ctx, dxy, dscore, n, (float)window, dindex, dcount);
+    if (rc) return rc;
+    STX_HIP(hipMemcpyAsync(count, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
+    STX_HIP(hipStreamSynchronize(s));
+    if (*count > 0) {
+        STX_HIP(hipMemcpyAsync(index_out, dindex, sizeof(int32_t) * (size_t)*count, hipMemcpyDeviceToHost, s));
+        STX_HIP(hipStreamSynchronize(s));
+    }
+    return STX_OK;
+}

@@ -71,3 +71,6 @@ int stx_launch_score_cluster(stx_ctx *ctx, const uint8_t *d_gx, const uint8_t *d
                              size_t stride, const float *d_xy, int n, const float kernel3x3[9],
                              float score_threshold, float cluster_dist, float *d_xy_out,
                              float *d_score_out, int32_t *d_index_out, int *d_count);
+
+int stx_launch_cluster(stx_ctx *ctx, const float *d_xy, const float *d_score, int n, float window,
+                       int32_t *d_index_out, int *d_count);

@@ -818,3 +818,20 @@ def test_score_cluster_dev_full_size(ctx, oracle):
     sub = 6000
     _score_equal(ctx.score_cluster(gx, gy, xy[:sub], k, 700.0, 2.0),
                  oracle.score_and_cluster(gx, gy, xy[:sub], k, 700.0, 2.0))
+
+
+@pytest.mark.parametrize("n,window", [(1, 20), (500, 2), (5000, 20), (30000, 20)])
+def test_cluster_features_matches_oracle(ctx, oracle, n, window):
+    """ClusterFeatures (Features.cpp:48-80, called with a 20-pixel window at :375)."""
+    rng = np.random.RandomState(n + window)
+    xy = (rng.rand(n, 2) * [741, 500]).astype(np.float32)
+    xy[: n // 2] = np.floor(xy[: n // 2])
+    score = rng.randint(0, 50, n).astype(np.float32) * 100 + 1     # many equal scores: all of a tie stay
+    score[rng.rand(n) < 0.01] = np.nan                              # NaN never compares less
+    got = ctx.cluster_features(xy, score, window)
+    want = oracle.cluster_features(xy, score, window)
+    assert got.tolist() == want.tolist()
+    assert len(ctx.cluster_features(np.zeros((0, 2), np.float32), np.zeros(0, np.float32), window)) == 0
+    feats = [api.Feature(p=(float(x), float(y)), score=float(s)) for (x, y), s in zip(xy[:200], score[:200])]
+    out = api.ClusterFeatures(feats, window, ctx=ctx)
+    assert [f.p for f in out] == [feats[i].p for i in oracle.cluster_features(xy[:200], score[:200], window)]

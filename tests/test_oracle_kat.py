@@ -385,3 +385,14 @@ def test_score_and_cluster_hand_case(oracle):
     plant(10, 5, 100); plant(12, 5, 150)
     _, _, idx2 = oracle.score_and_cluster(gx, gy, xy2, k, thr, 2.0)
     assert idx2.tolist() == [1]
+
+
+def test_cluster_features_hand_case(oracle):
+    # Features.cpp:61-65: (int)abs margins, <= window, strict < on scores; input order kept
+    xy = np.array([(10, 10), (12.9, 10), (16, 10), (10, 13), (40, 40), (40, 40)], np.float32)
+    score = np.array([5, 9, 7, 6, 3, 3], np.float32)
+    # window 2: 0 loses to 1 (2.9 -> 2); 2 is 3.1 from 1 -> 3 > 2, stays; 3 is 3 rows away, stays;
+    # the two equal features at (40, 40) both stay
+    assert oracle.cluster_features(xy, score, 2).tolist() == [1, 2, 3, 4, 5]
+    # window 3: 2 and 3 now see better neighbours (1 and ... 3 sees 0? score 6 > 5: no; sees 1: dx 2, dy 3 -> yes)
+    assert oracle.cluster_features(xy, score, 3).tolist() == [1, 4, 5]
