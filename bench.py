@@ -289,6 +289,17 @@ def main():
                         "within %d px, ordered by score" % (ncorn, W, H, api.ST_THRESH, api.NMS_WINDOW),
             "ms": ms, "features_per_s": ncorn / (ms * 1e-3), "survivors": int(s_ct.item()),
         }
+        # SIFT-like descriptors of the survivors
+        nsurv = int(s_ct.item())
+        d_ang = torch.zeros(nsurv, dtype=torch.float32, device="cuda")
+        d_desc = torch.empty((nsurv, 128), dtype=torch.float32, device="cuda")
+        sxy = s_xy[:nsurv].contiguous()
+        ms = event_time_ms(torch, lambda: ctx.sift_descriptors_dev(t_gx, t_gy, sxy, d_ang, d_desc), ks, kw)
+        extra["sift_descriptors"] = {
+            "workload": "128-float descriptors (orientation + 4x4 cells x 8 bins, normalise, clamp, renormalise) "
+                        "of the %d surviving features" % nsurv,
+            "ms": ms, "features_per_s": nsurv / (ms * 1e-3),
+        }
     if not args.no_extra:
         # descriptor matching (BASELINE config 5).  With N > 1 ranks list1's queries are sharded
         # (list2 replicated, no data-path collective): strong scaling of the one 200k x 200k job.
@@ -420,6 +431,14 @@ def main():
                 "sample": "oracle_score_and_cluster, first %d corners (%.2f s, single thread; O(n^2), so the "
                           "rate falls with n)" % (nsc, dt_s),
                 "matches_gpu_on_sample": bool(gs[2].tolist() == cs[2].tolist() and gs[1].tobytes() == cs[1].tobytes())}
+            t0 = time.perf_counter()
+            ca, cd = orc.sift_descriptors(gxy_np[0], gxy_np[1], sxy.cpu().numpy())
+            dt_d = time.perf_counter() - t0
+            ok_d = bool(np.array_equal(cd.view(np.uint32), d_desc.cpu().numpy().view(np.uint32)))
+            out["extra"]["cpu_sift_descriptors"] = {
+                "value": nsurv / dt_d, "unit": "features/s", "cores": 1,
+                "sample": "oracle_sift_descriptors, all %d features (%.2f s, single thread)" % (nsurv, dt_d),
+                "matches_gpu_on_sample": ok_d}
             # rectification: oracle_rectify on one image of the batch
             t0 = time.perf_counter()
             cr = orc.rectify(src_np[0], np.zeros((rh, rw), np.uint8), Hinv[0].reshape(3, 3))

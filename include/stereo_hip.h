@@ -243,6 +243,21 @@ int stx_cluster_features(stx_ctx *ctx, const float *xy, const float *score, int 
 int stx_cluster_features_dev(stx_ctx *ctx, const float *d_xy, const float *d_score, int n, int window,
                              int32_t *d_index_out, int *d_count);
 
+/* ---- SIFT-like descriptors (producer of stx_match's inputs) --------------------
+ * Replaces the per-feature body of CreateSIFTDescriptors (stereo/Features.cpp:844-934; decl
+ * Features.h:190-193; call Features.cpp:1204) and ComputeFeatureOrientation (:945-995), on the
+ * CV_8U gradient images of :830-837 (OpenCV's GaussianBlur + Sobel stay with the caller).
+ * xy: n (x, y) float pairs; angle: n floats, in/out (Feature::angle: set to the dominant
+ * orientation, kept when the 9x9 window holds no gradient); desc: n x 128 floats, out
+ * (Feature::desc).  atan is taken from a table that the library fills with the host's atanf
+ * once per context, so results follow the host libm as the reference's would.  Host pointers. */
+int stx_sift_descriptors(stx_ctx *ctx, const uint8_t *gx, const uint8_t *gy, int w, int h, size_t stride,
+                         const float *xy, int n, float *angle, float *desc);
+
+/* Device-resident form; asynchronous (the first call of a context uploads the tables). */
+int stx_sift_descriptors_dev(stx_ctx *ctx, const uint8_t *d_gx, const uint8_t *d_gy, int w, int h,
+                             size_t stride, const float *d_xy, int n, float *d_angle, float *d_desc);
+
 /* CreateGaussianKernel (stereo/Features.cpp:20-34) on the host: out[r * size + c]. */
 int stx_gaussian_kernel(int size, float sigma, float *out);
 

@@ -170,3 +170,18 @@ def cluster_features(xy, score, window):
     idx = np.zeros(max(n, 1), np.int32)
     m = lib().oracle_cluster_features(_p(xy), _p(score), n, int(window), _p(idx))
     return idx[:m].copy()
+
+
+def sift_descriptors(gx, gy, xy, angle=None):
+    gx = np.ascontiguousarray(gx, np.uint8)
+    gy = np.ascontiguousarray(gy, np.uint8)
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    n = xy.shape[0]
+    h, w = gx.shape
+    ang = np.zeros(max(n, 1), np.float32) if angle is None else np.array(angle, np.float32)
+    desc = np.zeros((max(n, 1), 128), np.float32)
+    k9 = gaussian_kernel(9, 1.0).reshape(81)
+    k4 = gaussian_kernel(4, 1.0).reshape(16)
+    lib().oracle_sift_descriptors(_p(gx), _p(gy), w, h, C.c_size_t(max(w, 1)), _p(xy), n, _p(k9), _p(k4),
+                                  _p(ang), _p(desc))
+    return ang[:n].copy(), desc[:n].copy()

@@ -609,3 +609,94 @@ int oracle_cluster_features(const float *xy, const float *score, int n, int wind
     }
     return kept;
 }
+
+/* ------------------------------------------------ SIFT-like descriptors --- */
+
+#define ORACLE_PI 3.14159f                                 /* Features.h:42 */
+#define ORACLE_RAD2DEG(A) ((A) * 180.f / ORACLE_PI)        /* :43 */
+#define ORACLE_DEG2RAD(A) ((A) * ORACLE_PI / 180.f)        /* :44 */
+
+/* Features.cpp:971-978 and :881-888: gradient magnitude and angle in degrees at one pixel */
+static void oracle_grad_polar(int vx, int vy, float *mag, float *angle)
+{
+    float gX = (float)vx, gY = (float)vy;
+    *mag = sqrtf(gX * gX + gY * gY);
+    if (gX != 0)
+        *angle = ORACLE_RAD2DEG(atanf(gY / gX)); /* atan of a float: the float overload */
+    else
+        *angle = 90;
+}
+
+/* Features.cpp:945-995 */
+void oracle_feature_orientation(const uint8_t *gx, const uint8_t *gy, int w, int h, size_t stride,
+                                float px, float py, const float k9[81], float *angle)
+{
+    float hist[36] = {0.0f}; /* ORIENTATION_HIST_BINS, :953 */
+    for (int n = -4; n <= 4; ++n) {     /* ANGLE_WINDOW / 2 = 4, :955 */
+        for (int m = -4; m <= 4; ++m) { /* :957 */
+            int i = n + (int)py;        /* :960 */
+            int j = m + (int)px;        /* :961 */
+            if (i < 0 || i >= h) continue; /* :964 */
+            if (j < 0 || j >= w) continue; /* :966 */
+            float mag, ang;
+            oracle_grad_polar(gx[(size_t)i * stride + j], gy[(size_t)i * stride + j], &mag, &ang);
+            hist[(int)(ang / 10)] += mag * k9[(n + 4) * 9 + (m + 4)]; /* :979 */
+        }
+    }
+    float dominant = 0; /* :985 */
+    for (int i = 0; i < 36; ++i) {
+        if (hist[i] > dominant) { /* :988 */
+            dominant = hist[i];
+            *angle = ORACLE_DEG2RAD(i * 10.f); /* :992 */
+        }
+    }
+}
+
+/* L2_norm<float>, Features.cpp:806-815, and NormaliseVector, :816-824 */
+static void oracle_normalise128(float *v)
+{
+    float norm = 0;
+    for (int i = 0; i < 128; ++i) norm += v[i] * v[i];
+    float s = sqrtf(norm);
+    for (int i = 0; i < 128; ++i) v[i] /= s;
+}
+
+/* Features.cpp:844-934 */
+void oracle_sift_descriptors(const uint8_t *gx, const uint8_t *gy, int w, int h, size_t stride,
+                             const float *xy, int n, const float k9[81], const float k4[16],
+                             float *angle, float *desc)
+{
+    for (int f = 0; f < n; ++f) {
+        float px = xy[2 * f], py = xy[2 * f + 1];
+        oracle_feature_orientation(gx, gy, w, h, stride, px, py, k9, &angle[f]); /* :849 */
+        float *vec = desc + (size_t)f * 128;
+        int entry = 0; /* :855 */
+        for (int j = 0; j < 16; j += 4) {     /* DESC_WINDOW, DESC_SUB_WINDOW, :860 */
+            for (int k = 0; k < 16; k += 4) { /* :862 */
+                float hist[8] = {0.0f};       /* DESC_BINS, :864 */
+                for (int nn = j; nn < j + 4; ++nn) {
+                    for (int m = k; m < k + 4; ++m) {
+                        int imgX = (int)px - 8 + m;  /* :870 */
+                        int imgY = (int)py - 8 + nn; /* :871 */
+                        if (imgY < 0 || imgY >= h) continue; /* :874 */
+                        if (imgX < 0 || imgX >= w) continue; /* :876 */
+                        float mag, ang;
+                        oracle_grad_polar(gx[(size_t)imgY * stride + imgX], gy[(size_t)imgY * stride + imgX],
+                                          &mag, &ang);
+                        ang -= angle[f];                         /* :890 degrees minus radians, as written */
+                        if (ang > 360) ang = (float)((int)ang % 360); /* :891-892 */
+                        if (ang < 0) ang = 0;                    /* :893-894 */
+                        int bin = (int)ang / 45;                 /* DESC_BIN_SIZE, :895 */
+                        if (bin > 7) bin = 7; /* ang == 360: the reference writes past hist[7] */
+                        hist[bin] += mag * k4[(j / 4) * 4 + (k / 4)];
+                    }
+                }
+                for (int index = 0; index < 8; ++index) vec[entry++] = hist[index]; /* :900-904 */
+            }
+        }
+        oracle_normalise128(vec); /* :910 */
+        for (int j = 0; j < 128; ++j)
+            if (vec[j] > 0.2f) vec[j] = 0.2f; /* ILLUMINANCE_BOUND, :920-926 */
+        oracle_normalise128(vec); /* :929 */
+    }
+}

@@ -141,6 +141,23 @@ int oracle_score_and_cluster(const uint8_t *gx, const uint8_t *gy, int w, int h,
                              float score_threshold, float cluster_dist, float *xy_out,
                              float *score_out, int32_t *index_out);
 
+/* ---- SIFT-like descriptors (third part) ------------------------
+ * ComputeFeatureOrientation, stereo/Features.cpp:945-995: 36-bin orientation histogram over
+ * the 9x9 window (ANGLE_WINDOW, Features.h:26) of the CV_8U gradient images, weighted by
+ * magnitude and by k9 = CreateGaussianKernel(9, 1); *angle takes DEG2RAD(10 * dominant bin)
+ * and keeps its prior value when every bin is 0 (the reference leaves it uninitialised). */
+void oracle_feature_orientation(const uint8_t *gx, const uint8_t *gy, int w, int h, size_t stride,
+                                float px, float py, const float k9[81], float *angle);
+
+/* The per-feature body of CreateSIFTDescriptors, stereo/Features.cpp:844-934, after the
+ * OpenCV filters (:830-837): orientation, 4x4 cells x 8 bins over the 16x16 window with the
+ * feature at (8, 8), k4 = CreateGaussianKernel(4, 1) cell weights, normalise, clamp at 0.2
+ * (ILLUMINANCE_BOUND), renormalise.  angle: n values, in/out; desc: n x 128, out.  The
+ * reference mixes units at :890 (angle in degrees minus f.angle in radians); kept. */
+void oracle_sift_descriptors(const uint8_t *gx, const uint8_t *gy, int w, int h, size_t stride,
+                             const float *xy, int n, const float k9[81], const float k4[16],
+                             float *angle, float *desc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@ from .api import (
     FindFASTFeatures,
     ScoreAndClusterFeatures,
     ClusterFeatures,
+    CreateSIFTDescriptors,
     RectifyImage,
     ComputeDepthImage,
     MATCH_FAILED,
@@ -30,7 +31,7 @@ from .api import (
 
 __all__ = [
     "StereoHipError", "load_library", "library_path", "Context", "Feature",
-    "MatchDescriptors", "FindFASTFeatures", "ScoreAndClusterFeatures", "ClusterFeatures", "RectifyImage", "ComputeDepthImage",
+    "MatchDescriptors", "FindFASTFeatures", "ScoreAndClusterFeatures", "ClusterFeatures", "CreateSIFTDescriptors", "RectifyImage", "ComputeDepthImage",
     "MATCH_FAILED", "MATCH_SCORE", "MATCH_RATIO", "MATCH_ACCEPTED",
     "NN_RATIO", "MAX_DIST_BETWEEN_MATCHES",
 ]

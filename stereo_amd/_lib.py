@@ -71,6 +71,8 @@ PROTOTYPES = {
                                         C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
     "stx_cluster_features": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.POINTER(C.c_int)]),
     "stx_cluster_features_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "stx_sift_descriptors": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_int, _vp, _vp]),
+    "stx_sift_descriptors_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_int, _vp, _vp]),
     "stx_gaussian_kernel": (C.c_int, [C.c_int, C.c_float, _f32p]),
     "stx_rectify_disparity_u8": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_size_t, _f32p, _f32p,
                                            C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp, _vp,

@@ -140,6 +140,35 @@ inline std::vector<Feature> ScoreAndClusterFeaturesOnGradients(const cv::Mat &gr
     return good;
 }
 
+// The per-feature body of CreateSIFTDescriptors (Features.h:190-193, Features.cpp:827-937) on
+// the CV_8U gradient images of :830-837; the drop-in keeps the reference's three OpenCV calls
+// in front of it.  Sets angle and desc of every feature, appends the
+// descriptors.
+inline bool CreateSIFTDescriptorsOnGradients(const cv::Mat &grad_x, const cv::Mat &grad_y,
+                                             std::vector<Feature> &features,
+                                             std::vector<FeatureDescriptor> &descriptors)
+{
+    using namespace stereo_hip_dropin;
+    const int n = (int)features.size();
+    if (n == 0) return true;
+    if (grad_x.cols != grad_y.cols || grad_x.rows != grad_y.rows || grad_x.step != grad_y.step) return false;
+    std::vector<float> xy(2 * (size_t)n), angle((size_t)n), desc(128 * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        xy[2 * (size_t)i] = features[i].p.x;
+        xy[2 * (size_t)i + 1] = features[i].p.y;
+        angle[i] = features[i].angle;
+    }
+    check(stx_sift_descriptors(context(), grad_x.data, grad_y.data, grad_x.cols, grad_x.rows, (size_t)grad_x.step,
+                               xy.data(), n, angle.data(), desc.data()),
+          "stx_sift_descriptors");
+    for (int i = 0; i < n; ++i) {
+        features[i].angle = angle[i];
+        for (int k = 0; k < 128; ++k) features[i].desc.vec[k] = desc[128 * (size_t)i + k];
+        descriptors.push_back(features[i].desc);  // :933
+    }
+    return true;
+}
+
 // Stereography.h:48-51.  H is the forward homography; `rectified` is in/out.
 inline void RectifyImage(const cv::Mat &original, cv::Mat &rectified, const Eigen::Matrix3f &H)
 {

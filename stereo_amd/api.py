@@ -216,6 +216,32 @@ class Context:
         m = cnt.value
         return oxy[:m], osc[:m], oidx[:m]
 
+    def sift_descriptors(self, grad_x, grad_y, xy, angle=None):
+        """(angle [n], desc [n,128]) for the features at xy; `angle` gives the prior
+        Feature::angle values (kept where the orientation window holds no gradient)."""
+        _check_image(grad_x, "grad_x")
+        _check_image(grad_y, "grad_y")
+        if grad_x.shape != grad_y.shape or grad_x.strides != grad_y.strides:
+            raise ValueError("grad_x and grad_y must have the same shape and pitch")
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        n = xy.shape[0]
+        ang = np.zeros(max(n, 1), np.float32)
+        if angle is not None:
+            ang[:n] = np.asarray(angle, np.float32)
+        desc = np.zeros((max(n, 1), DESC_LENGTH), np.float32)
+        h, w = grad_x.shape
+        check(self._lib.stx_sift_descriptors(self._h, _ptr(grad_x), _ptr(grad_y), w, h,
+                                             grad_x.strides[0] if h > 1 else max(w, 1), _ptr(xy), n,
+                                             _ptr(ang), _ptr(desc)), "stx_sift_descriptors")
+        return ang[:n], desc[:n]
+
+    def sift_descriptors_dev(self, grad_x, grad_y, xy, angle, desc):
+        """Device tensors: grad_* [H,W] uint8, xy [n,2] float32, angle [n] (in/out), desc [n,128]."""
+        check(self._lib.stx_sift_descriptors_dev(self._h, grad_x.data_ptr(), grad_y.data_ptr(),
+                                                 int(grad_x.shape[1]), int(grad_x.shape[0]),
+                                                 int(grad_x.stride(0)), xy.data_ptr(), int(xy.shape[0]),
+                                                 angle.data_ptr(), desc.data_ptr()), "stx_sift_descriptors_dev")
+
     def cluster_features(self, xy, score, window):
         """Input positions of the features that survive ClusterFeatures, in input order."""
         xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
@@ -372,6 +398,19 @@ def FindFASTFeatures(img, features, ctx=None):
     xy, _ = ctx.fast_detect(img, FAST_THRESHOLD)
     for x, y in xy:
         features.append(Feature(p=(float(x), float(y))))
+    return True
+
+
+def CreateSIFTDescriptors(grad_x, grad_y, features, descriptors, ctx=None):
+    """CreateSIFTDescriptors, stereo/Features.cpp:827-937, on the CV_8U gradient images of
+    :830-837: sets angle and desc of every feature in place and appends the descriptors."""
+    ctx = ctx or default_context()
+    xy = np.array([f.p for f in features], np.float32).reshape(-1, 2)
+    ang, desc = ctx.sift_descriptors(grad_x, grad_y, xy, [f.angle for f in features])
+    for f, a, d in zip(features, ang, desc):
+        f.angle = float(a)
+        f.desc = d.copy()
+        descriptors.append(f.desc)
     return True
 
 

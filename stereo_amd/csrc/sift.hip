@@ -1,0 +1,163 @@
+// SIFT-like descriptors for gfx950: the per-feature body of CreateSIFTDescriptors
+// (stereo/Features.cpp:844-934) with ComputeFeatureOrientation (:945-995), on the CV_8U
+// gradient images the reference makes with OpenCV's GaussianBlur and Sobel (:830-837; they
+// stay with the caller).  Output: the 128-float descriptors that MatchDescriptors consumes.
+//
+// Bit-exactness.  The only transcendental on the path is atan(gY / gX) of two gradient BYTES
+// (:976, :886), i.e. one of 65 536 values: the host tabulates RAD2DEG(atanf(gY / gX)) once per
+// context with its own libm -- the function the reference's host code would call -- and the
+// kernel looks the angle up, so the result follows the host's libm exactly, whatever it is.
+// Everything else (magnitude sqrt, the kernel weights, histogram accumulation in the
+// reference's tap order, the two normalisations with their sequential sums of squares and
+// true divisions, the 0.2 clamp) is kept as separately rounded fp32 operations
+// (-ffp-contract=off).  Kept as written: the angle in DEGREES minus f.angle in RADIANS
+// (:890), PI = 3.14159f (Features.h:42), the Gaussian kernels centred at size/2.f.
+//
+// One lane per feature (the histogram updates of a feature are order dependent); the
+// histograms live in LDS, one column per lane.  Gradient bytes are >= 0, so the tabulated
+// angles lie in [0, 90.0001]: the orientation histogram can only reach bins 0..9 of its 36.
+#include "stx_internal.h"
+
+#include <math.h>
+#include <vector>
+
+namespace {
+
+constexpr int SIFT_THREADS = 64;
+constexpr int SIFT_OBINS = 10;  // reachable bins of the 36-bin orientation histogram
+constexpr float SIFT_PI = 3.14159f;  // Features.h:42
+
+__global__ __launch_bounds__(SIFT_THREADS) void sift_kernel(
+    const uint8_t *__restrict__ gx, const uint8_t *__restrict__ gy, int w, int h, size_t stride,
+    const float2 *__restrict__ xy, int n, const float *__restrict__ tables, float *__restrict__ angle,
+    float *__restrict__ desc)
+{
+    __shared__ float ohist[SIFT_OBINS][SIFT_THREADS];
+    __shared__ float chist[8][SIFT_THREADS];
+    const float *lut = tables;           // [gy][gx] angle in degrees, 90 where gx == 0
+    const float *k9 = tables + 65536;    // CreateGaussianKernel(9, 1)
+    const float *k4 = k9 + 81;           // CreateGaussianKernel(4, 1)
+    const int t = threadIdx.x;
+    const int f = blockIdx.x * SIFT_THREADS + t;
+    if (f >= n) return;
+    const float2 p = xy[f];
+    const int cx = (int)p.x, cy = (int)p.y;
+
+    // ---- ComputeFeatureOrientation, :945-995 --------------------------------
+#pragma unroll
+    for (int b = 0; b < SIFT_OBINS; ++b) ohist[b][t] = 0.0f;
+    for (int nn = -4; nn <= 4; ++nn) {
+        const int i = nn + cy;
+        if (i < 0 || i >= h) continue;  // :964
+        for (int m = -4; m <= 4; ++m) {
+            const int j = m + cx;
+            if (j < 0 || j >= w) continue;  // :966
+            const int vx = gx[(size_t)i * stride + j], vy = gy[(size_t)i * stride + j];
+            const float gX = (float)vx, gY = (float)vy;
+            const float mag = sqrtf(gX * gX + gY * gY);  // :973
+            const float ang = lut[vy * 256 + vx];        // :974-978
+            const int bin = (int)(ang / 10.f);
+            ohist[bin][t] = ohist[bin][t] + mag * k9[(nn + 4) * 9 + (m + 4)];  // :979
+        }
+    }
+    float fang = angle[f];  // kept when every bin is 0
+    float dominant = 0.f;
+#pragma unroll
+    for (int b = 0; b < SIFT_OBINS; ++b) {
+        const float v = ohist[b][t];
+        if (v > dominant) {  // :988
+            dominant = v;
+            fang = (float)b * 10.f * SIFT_PI / 180.f;  // DEG2RAD(i * 10.f), :992
+        }
+    }
+    angle[f] = fang;
+
+    // ---- 4x4 cells x 8 bins, :860-906 ----------------------------------------
+    float *vec = desc + (size_t)f * 128;
+    int entry = 0;
+    for (int j = 0; j < 16; j += 4) {
+        for (int k = 0; k < 16; k += 4) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) chist[b][t] = 0.0f;
+            const float wgt = k4[(j / 4) * 4 + (k / 4)];
+            for (int nn = j; nn < j + 4; ++nn) {
+                const int imgY = cy - 8 + nn;  // :871
+                if (imgY < 0 || imgY >= h) continue;
+                for (int m = k; m < k + 4; ++m) {
+                    const int imgX = cx - 8 + m;  // :870
+                    if (imgX < 0 || imgX >= w) continue;
+                    const int vx = gx[(size_t)imgY * stride + imgX], vy = gy[(size_t)imgY * stride + imgX];
+                    const float gX = (float)vx, gY = (float)vy;
+                    const float mag = sqrtf(gX * gX + gY * gY);  // :883
+                    float ang = lut[vy * 256 + vx];              // :884-888
+                    ang = ang - fang;                            // :890
+                    if (ang > 360.f) ang = (float)((int)ang % 360);  // :891-892
+                    if (ang < 0.f) ang = 0.f;                    // :893-894
+                    int bin = (int)ang / 45;                     // :895
+                    if (bin > 7) bin = 7;  // ang == 360: the reference writes past hist[7]
+                    chist[bin][t] = chist[bin][t] + mag * wgt;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) vec[entry + b] = chist[b][t];  // :900-904
+            entry += 8;
+        }
+    }
+
+    // ---- normalise, clamp at 0.2, renormalise, :909-932 -----------------------
+    float norm = 0.f;
+    for (int i = 0; i < 128; ++i) {  // L2_norm, :806-815
+        const float v = vec[i];
+        norm = norm + v * v;
+    }
+    const float s = sqrtf(norm);
+    float norm2 = 0.f;
+    for (int i = 0; i < 128; ++i) {
+        float v = vec[i] / s;        // :822
+        if (v > 0.2f) v = 0.2f;      // ILLUMINANCE_BOUND, :922-925
+        vec[i] = v;
+        norm2 = norm2 + v * v;
+    }
+    const float s2 = sqrtf(norm2);
+    for (int i = 0; i < 128; ++i) vec[i] = vec[i] / s2;
+}
+
+}  // namespace
+
+// [lut 65536][k9 81][k4 16] floats, built once per context with the host's libm
+static int sift_tables(stx_ctx *ctx, const float **d_tables)
+{
+    const size_t count = 65536 + 81 + 16;
+    int err;
+    const bool built = ctx->slot_bytes[STX_SLOT_SIFT_TABLES] >= sizeof(float) * count;
+    float *d = (float *)stx_workspace(ctx, STX_SLOT_SIFT_TABLES, sizeof(float) * count, &err);
+    if (!d) return err;
+    if (!built) {
+        std::vector<float> host(count);
+        for (int vy = 0; vy < 256; ++vy)
+            for (int vx = 0; vx < 256; ++vx) {
+                const float gX = (float)vx, gY = (float)vy;
+                // :974-978; atan of a float argument is the float overload in the reference's C++
+                host[(size_t)vy * 256 + vx] = vx != 0 ? atanf(gY / gX) * 180.f / SIFT_PI : 90.f;
+            }
+        int rc = stx_gaussian_kernel(9, 1.f, host.data() + 65536);
+        if (rc) return rc;
+        rc = stx_gaussian_kernel(4, 1.f, host.data() + 65536 + 81);
+        if (rc) return rc;
+        STX_HIP(hipMemcpy(d, host.data(), sizeof(float) * count, hipMemcpyHostToDevice));
+    }
+    *d_tables = d;
+    return STX_OK;
+}
+
+int stx_launch_sift(stx_ctx *ctx, const uint8_t *d_gx, const uint8_t *d_gy, int w, int h, size_t stride,
+                    const float *d_xy, int n, float *d_angle, float *d_desc)
+{
+    if (n <= 0) return STX_OK;
+    const float *tables = nullptr;
+    int rc = sift_tables(ctx, &tables);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sift_kernel, dim3((n + SIFT_THREADS - 1) / SIFT_THREADS), dim3(SIFT_THREADS), 0, ctx->stream,
+                       d_gx, d_gy, w, h, stride, reinterpret_cast<const float2 *>(d_xy), n, tables, d_angle, d_desc);
+    return (int)hipGetLastError();
+}

@@ -621,3 +621,53 @@ extern "C" int stx_cluster_features(stx_ctx *ctx, const float *xy, const float *
     }
     return STX_OK;
 }
+
+// ------------------------------------------------------------ descriptors --
+
+extern "C" int stx_sift_descriptors_dev(stx_ctx *ctx, const uint8_t *d_gx, const uint8_t *d_gy, int w, int h,
+                                        size_t stride, const float *d_xy, int n, float *d_angle, float *d_desc)
+{
+    if (!ctx || n < 0) return STX_ERR_INVALID_ARG;
+    if (n > 0 && (!d_xy || !d_angle || !d_desc)) return STX_ERR_INVALID_ARG;
+    int rc = check_image(d_gx, w, h, stride);
+    if (rc) return rc;
+    rc = check_image(d_gy, w, h, stride);
+    if (rc) return rc;
+    STX_HIP(hipSetDevice(ctx->device));
+    return stx_launch_sift(ctx, d_gx, d_gy, w, h, stride, d_xy, n, d_angle, d_desc);
+}
+
+extern "C" int stx_sift_descriptors(stx_ctx *ctx, const uint8_t *gx, const uint8_t *gy, int w, int h,
+                                    size_t stride, const float *xy, int n, float *angle, float *desc)
+{
+    if (!ctx || n < 0) return STX_ERR_INVALID_ARG;
+    if (n > 0 && (!xy || !angle || !desc)) return STX_ERR_INVALID_ARG;
+    int rc = check_image(gx, w, h, stride);
+    if (rc) return rc;
+    rc = check_image(gy, w, h, stride);
+    if (rc) return rc;
+    if (n == 0) return STX_OK;
+    STX_HIP(hipSetDevice(ctx->device));
+    int err;
+    hipStream_t s = ctx->stream;
+    const size_t p = (size_t)(w > 0 ? w : 1), img = (p * (size_t)(h > 0 ? h : 1) + 15) & ~(size_t)15;
+    // [gx][gy][xy n*2][angle n][desc n*128]
+    uint8_t *base = (uint8_t *)stx_workspace(ctx, STX_SLOT_SCORE_IO, 2 * img + sizeof(float) * (size_t)n * 131, &err);
+    if (!base) return err;
+    uint8_t *dgx = base, *dgy = base + img;
+    float *dxy = reinterpret_cast<float *>(base + 2 * img);
+    float *dangle = dxy + 2 * (size_t)n;
+    float *ddesc = dangle + n;
+    if (w > 0 && h > 0) {
+        STX_HIP(copy_image_h2d(dgx, p, gx, stride, (size_t)w, (size_t)h, s));
+        STX_HIP(copy_image_h2d(dgy, p, gy, stride, (size_t)w, (size_t)h, s));
+    }
+    STX_HIP(hipMemcpyAsync(dxy, xy, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, s));
+    STX_HIP(hipMemcpyAsync(dangle, angle, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, s));
+    rc = stx_launch_sift(ctx, dgx, dgy, w, h, p, dxy, n, dangle, ddesc);
+    if (rc) return rc;
+    STX_HIP(hipMemcpyAsync(angle, dangle, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, s));
+    STX_HIP(hipMemcpyAsync(desc, ddesc, sizeof(float) * 128 * (size_t)n, hipMemcpyDeviceToHost, s));
+    STX_HIP(hipStreamSynchronize(s));
+    return STX_OK;
+}

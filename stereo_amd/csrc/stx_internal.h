@@ -24,6 +24,7 @@ enum stx_slot {
     STX_SLOT_FAST,       // FAST: corner bit words + prefix sums
     STX_SLOT_SCORE,      // scoring + NMS: scores, index lists, flags, counts
     STX_SLOT_SCORE_IO,   // host-API staging of the scoring call: gradient images, features, outputs
+    STX_SLOT_SIFT_TABLES, // descriptors: atan table + Gaussian kernels (built once per context)
     STX_SLOT_COUNT
 };
 
@@ -71,6 +72,9 @@ int stx_launch_score_cluster(stx_ctx *ctx, const uint8_t *d_gx, const uint8_t *d
                              size_t stride, const float *d_xy, int n, const float kernel3x3[9],
                              float score_threshold, float cluster_dist, float *d_xy_out,
                              float *d_score_out, int32_t *d_index_out, int *d_count);
+
+int stx_launch_sift(stx_ctx *ctx, const uint8_t *d_gx, const uint8_t *d_gy, int w, int h, size_t stride,
+                    const float *d_xy, int n, float *d_angle, float *d_desc);
 
 int stx_launch_cluster(stx_ctx *ctx, const float *d_xy, const float *d_score, int n, float window,
                        int32_t *d_index_out, int *d_count);

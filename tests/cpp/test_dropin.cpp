@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <sstream>
 
 // struct Feature as the reference declares it (stereo/Features.h:46-84), minus stream operators
@@ -149,6 +150,19 @@ int main()
         for (int i = 0; i < m && i < (int)good.size(); ++i)
             if (good[i].p.x != oxy[2 * i] || good[i].p.y != oxy[2 * i + 1] || good[i].score != osc[i]) ++fails;
         std::printf("score+NMS fails so far: %d (survivors %d of %d)\n", fails, m, n);
+        // descriptors of the survivors
+        std::vector<FeatureDescriptor> descs;
+        if (!CreateSIFTDescriptorsOnGradients(gx, gy, good, descs) || (int)descs.size() != m) ++fails;
+        float k9[81], k4[16];
+        oracle_gaussian_kernel(9, 1.f, k9);
+        oracle_gaussian_kernel(4, 1.f, k4);
+        std::vector<float> oang(m, 0.f), odesc(128 * (size_t)m);
+        oracle_sift_descriptors(gx.data, gy.data, w, h, gx.step, oxy.data(), m, k9, k4, oang.data(), odesc.data());
+        for (int i = 0; i < m && i < (int)good.size(); ++i) {
+            if (good[i].angle != oang[i]) ++fails;
+            if (std::memcmp(good[i].desc.vec, &odesc[128 * (size_t)i], 512) != 0) ++fails;
+        }
+        std::printf("descriptor fails so far: %d\n", fails);
     }
     std::printf(fails ? "DROPIN FAIL\n" : "DROPIN OK\n");
     return fails ? 1 : 0;

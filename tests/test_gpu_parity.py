@@ -835,3 +835,73 @@ def test_cluster_features_matches_oracle(ctx, oracle, n, window):
     feats = [api.Feature(p=(float(x), float(y)), score=float(s)) for (x, y), s in zip(xy[:200], score[:200])]
     out = api.ClusterFeatures(feats, window, ctx=ctx)
     assert [f.p for f in out] == [feats[i].p for i in oracle.cluster_features(xy[:200], score[:200], window)]
+
+
+# ------------------------------------------ SIFT-like descriptors (N3, third part) ------
+
+def _desc_equal(got, want):
+    for g, w_ in zip(got, want):
+        gb, wb = g.view(np.uint32), w_.view(np.uint32)
+        ok = (gb == wb) | (np.isnan(g) & np.isnan(w_))
+        assert ok.all(), np.argwhere(~ok)[:8]
+
+
+@pytest.mark.parametrize("h,w,n", [(40, 50, 1), (60, 80, 500), (500, 741, 6000)])
+def test_sift_descriptors_match_oracle(ctx, oracle, h, w, n):
+    gx, gy = _grad_images(h * 3 + n, h, w)
+    gx[5:30, 5:30] = 0
+    gy[5:30, 5:30] = 0                       # a gradient-free patch: angle kept, descriptor NaN
+    rng = np.random.RandomState(n)
+    xy = np.stack([rng.randint(0, w, n), rng.randint(0, h, n)], 1).astype(np.float32)
+    xy[: n // 3] += rng.rand(n // 3, 2).astype(np.float32) * 0.9
+    xy[-1] = (17, 17)
+    ang0 = rng.rand(n).astype(np.float32)
+    got = ctx.sift_descriptors(gx, gy, xy, ang0)
+    want = oracle.sift_descriptors(gx, gy, xy, ang0)
+    _desc_equal(got, want)
+    assert want[0][-1] == ang0[-1] and np.isnan(want[1][-1]).all()
+    if n > 1:
+        norms = np.linalg.norm(got[1][~np.isnan(got[1]).any(axis=1)], axis=1)
+        assert np.abs(norms - 1).max() < 1e-5
+
+
+def test_sift_descriptors_extreme_prior_angles(ctx, oracle):
+    """f.angle is uninitialised in the reference when the 9x9 window has no gradient; whatever
+    it holds goes through :890-895 (negative values push the relative angle up to the
+    (int)angle % 360 branch and the last bin)."""
+    gx = np.zeros((60, 60), np.uint8); gy = np.zeros((60, 60), np.uint8)
+    gx[:, 40:] = 200; gy[:, 40:] = 37      # gradients only to the right of column 40
+    xy = np.array([(33, 30)] * 8, np.float32)   # orientation window [29, 37] is gradient-free
+    # (beyond +-2^31 the reference's (int)angle is undefined behaviour: not tested)
+    ang0 = np.array([0, -100, -269.9, -270, -271, -500, 2e9, -2e9], np.float32)
+    _desc_equal(ctx.sift_descriptors(gx, gy, xy, ang0), oracle.sift_descriptors(gx, gy, xy, ang0))
+
+
+def test_feature_chain_fast_score_describe_match(ctx, oracle):
+    """GetImageDescriptorsForImages (Features.cpp:1171-1214) + MatchDescriptors (main.cpp:207) with
+    every in-tree stage on the GPU: FAST -> score + NMS -> descriptors, for two images, -> match."""
+    h, w = 240, 320
+    left, right = synth.rectified_pair(31, h, w, 24)
+    lists = []
+    for k, img in enumerate((left, right)):
+        gx, gy = _grad_images(40 + k, h, w)   # stand-ins for OpenCV's GaussianBlur + Sobel outputs
+        feats = []
+        api.FindFASTFeatures(img, feats, ctx=ctx)
+        feats = api.ScoreAndClusterFeatures(gx, gy, feats, api.ST_THRESH, api.NMS_WINDOW, ctx=ctx)
+        descs = []
+        assert api.CreateSIFTDescriptors(gx, gy, feats, descs, ctx=ctx) and len(descs) == len(feats)
+        # the same chain through the oracle
+        oxy = oracle.fast_features(img)
+        sxy, ssc, _ = oracle.score_and_cluster(gx, gy, oxy, oracle.gaussian_kernel(3, 1.0), 700.0, 2.0)
+        oang, odesc = oracle.sift_descriptors(gx, gy, sxy)
+        assert [f.p for f in feats] == [tuple(map(float, p)) for p in sxy]
+        _desc_equal((np.array([f.angle for f in feats], np.float32), np.stack([f.desc for f in feats])),
+                    (oang, odesc))
+        lists.append((feats, sxy, ssc, odesc))
+    assert len(lists[0][0]) > 50 and len(lists[1][0]) > 50
+    matches = api.MatchDescriptors(lists[0][0], lists[1][0], 1000.0, ctx=ctx)
+    want = oracle.match(lists[0][3], lists[0][2], lists[1][3], lists[1][2], 1000.0)
+    acc = np.nonzero(want[4] == api.MATCH_ACCEPTED)[0]
+    assert len(matches) == len(acc)
+    for (a, b), i in zip(matches, acc):
+        assert a.p == tuple(map(float, lists[0][1][i])) and b.p == tuple(map(float, lists[1][1][want[0][i]]))

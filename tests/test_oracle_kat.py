@@ -396,3 +396,103 @@ def test_cluster_features_hand_case(oracle):
     assert oracle.cluster_features(xy, score, 2).tolist() == [1, 2, 3, 4, 5]
     # window 3: 2 and 3 now see better neighbours (1 and ... 3 sees 0? score 6 > 5: no; sees 1: dx 2, dy 3 -> yes)
     assert oracle.cluster_features(xy, score, 3).tolist() == [1, 4, 5]
+
+
+# ------------------------------------------- SIFT-like descriptors (N3) ------
+
+def _sift_np(gx, gy, x, y, angle0, k9, k4):
+    """Features.cpp:844-934 + :945-995 restated a second time: numpy float32 scalars, every
+    operation rounded, atanf taken from the C library (as the oracle and the reference do)."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.atanf.restype = ctypes.c_float
+    libm.atanf.argtypes = [ctypes.c_float]
+    f = np.float32
+    PI = f(3.14159)
+    h, w = gx.shape
+    cx, cy = int(x), int(y)
+
+    def polar(vx, vy):
+        gX, gY = f(vx), f(vy)
+        mag = f(np.sqrt(f(f(gX * gX) + f(gY * gY))))
+        ang = f(f(f(libm.atanf(f(gY / gX))) * f(180)) / PI) if vx != 0 else f(90)
+        return mag, ang
+
+    hist = [f(0)] * 36
+    for n in range(-4, 5):
+        for m in range(-4, 5):
+            i, j = n + cy, m + cx
+            if i < 0 or i >= h or j < 0 or j >= w:
+                continue
+            mag, ang = polar(int(gx[i, j]), int(gy[i, j]))
+            b = int(f(ang / f(10)))
+            hist[b] = f(hist[b] + f(mag * k9[n + 4, m + 4]))
+    angle, dom = f(angle0), f(0)
+    for i in range(36):
+        if hist[i] > dom:
+            dom = hist[i]
+            angle = f(f(f(f(i) * f(10)) * PI) / f(180))
+    vec = []
+    for j in range(0, 16, 4):
+        for k in range(0, 16, 4):
+            hs = [f(0)] * 8
+            for n in range(j, j + 4):
+                for m in range(k, k + 4):
+                    ix, iy = cx - 8 + m, cy - 8 + n
+                    if iy < 0 or iy >= h or ix < 0 or ix >= w:
+                        continue
+                    mag, ang = polar(int(gx[iy, ix]), int(gy[iy, ix]))
+                    ang = f(ang - angle)
+                    if ang > 360:
+                        ang = f(int(ang) % 360)
+                    if ang < 0:
+                        ang = f(0)
+                    b = min(int(ang) // 45, 7)
+                    hs[b] = f(hs[b] + f(mag * k4[j // 4, k // 4]))
+            vec += hs
+
+    def normalise(v):
+        norm = f(0)
+        for a in v:
+            norm = f(norm + f(a * a))
+        s = f(np.sqrt(norm))
+        with np.errstate(all="ignore"):
+            return [f(a / s) for a in v]
+
+    vec = normalise(vec)
+    vec = [f(0.2) if a > f(0.2) else a for a in vec]
+    return angle, np.array(normalise(vec), np.float32)
+
+
+def test_sift_descriptor_hand_case(oracle):
+    # gx == gy everywhere: every gradient points at 45 degrees (:976) -> orientation bin 4 ->
+    # f.angle = DEG2RAD(40) (:992) = 40 * 3.14159f / 180; every tap then falls into descriptor
+    # bin (int)(45 - 0.698) / 45 = 0 (:890-895), so each cell has one non-zero entry
+    gx = np.full((40, 40), 30, np.uint8)
+    ang, desc = oracle.sift_descriptors(gx, gx, np.array([(20, 20)], np.float32))
+    assert ang[0] == np.float32(np.float32(40.0) * np.float32(3.14159) / np.float32(180))
+    d = desc[0].reshape(16, 8)
+    assert (d[:, 1:] == 0).all() and (d[:, 0] > 0).all()
+    assert abs(np.linalg.norm(desc[0]) - 1) < 1e-6
+    # cell weights are CreateGaussianKernel(4, 1) (:840-841, :895), centred at cell (2, 2); the
+    # nine cells around it exceed 0.2 after the first normalisation and are clamped equal (:922)
+    c = d[:, 0].reshape(4, 4)
+    assert c[0, 0] < c[0, 1] < c[0, 2] and c[0, 1] == c[0, 3] == c[1, 0]
+    assert (c[1:, 1:] == c[2, 2]).all() and c[2, 2] > c[0, 2]
+    # no gradient at all: angle keeps its prior value, the descriptor is 0/0 = NaN (:822)
+    z = np.zeros((40, 40), np.uint8)
+    ang, desc = oracle.sift_descriptors(z, z, np.array([(20, 20)], np.float32), angle=[1.25])
+    assert ang[0] == np.float32(1.25) and np.isnan(desc).all()
+
+
+def test_sift_descriptor_matches_second_restatement_bit_for_bit(oracle):
+    rng = np.random.RandomState(4)
+    gx = np.clip(rng.randn(50, 60) * 60, 0, 255).astype(np.uint8)
+    gy = np.clip(rng.randn(50, 60) * 60, 0, 255).astype(np.uint8)
+    k9, k4 = oracle.gaussian_kernel(9, 1.0), oracle.gaussian_kernel(4, 1.0)
+    pts = [(25, 25), (3, 4), (58, 47), (30.7, 20.2), (0, 0), (59, 49), (10, 44)]
+    ang, desc = oracle.sift_descriptors(gx, gy, np.array(pts, np.float32), angle=[0.5] * len(pts))
+    for i, (x, y) in enumerate(pts):
+        a2, d2 = _sift_np(gx, gy, x, y, 0.5, k9, k4)
+        assert np.float32(ang[i]).tobytes() == np.float32(a2).tobytes()
+        assert desc[i].tobytes() == d2.tobytes(), (i, np.abs(desc[i] - d2).max())
