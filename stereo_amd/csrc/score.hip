@@ -13,16 +13,19 @@
 //   score_kernel      one lane per feature: score, keep = score > threshold, kept per tile
 //   compact_kernel    order-preserving compaction of the kept features (tile prefix by a
 //                     short loop over the tile counts, in-tile prefix by ballots)
-//   nms_kernel        one lane per kept feature against all kept features, staged through
-//                     LDS in tiles; keep = no strictly better feature inside the window
+//   nms_kernel        kept x kept pair space in 256 x 256 tiles over a 2-D grid; a lane that
+//                     finds a strictly better feature inside the window sets suppressed[a]
+//   nms_count_kernel  flags + kept-per-tile counts
 //   compact_kernel    survivors, still in input order
-//   rank_kernel       rank = number of survivors with a larger score (ties: earlier input
-//                     position first), scatter to the output -- a deterministic sort
+//   rank_kernel       same tiling: partial rank = number of survivors with a larger score
+//                     (ties: earlier input position first), summed with integer atomics
+//   rank_scatter      output[rank] = survivor -- a deterministic sort
 #include "stx_internal.h"
 
 namespace {
 
 constexpr int SC_THREADS = 256;
+constexpr int SC_SLICES = 64;  // b-tile slices of the O(n^2) kernels (grid.y)
 
 struct Kernel3x3 {
     float w[9];
@@ -132,15 +135,18 @@ __global__ __launch_bounds__(SC_THREADS) void compact_kernel(
 
 // Features.cpp:752-778 over the kept features good[0 .. *ngood): feature a survives unless a
 // kept feature b != a lies within `dist` on both axes and has a strictly larger score.
+// The O(n^2) pair space is cut into tiles of SC_THREADS x SC_THREADS: block (x, y) holds the
+// a-tile x and walks the b-tiles y, y + gridDim.y, ...; a lane that finds a better neighbour
+// sets suppressed[a] (every writer stores the same 1: no ordering issue).
 __global__ __launch_bounds__(SC_THREADS) void nms_kernel(
     const float2 *__restrict__ xy, const float *__restrict__ score, const int *__restrict__ good, int n,
-    const int *__restrict__ ngood, float dist, uint8_t *__restrict__ keep, int *__restrict__ tile_counts)
+    const int *__restrict__ ngood, float dist, uint8_t *__restrict__ suppressed)
 {
     // good == null: the kept list is the whole input list (ClusterFeatures); ngood == null: n
     __shared__ float sx[SC_THREADS], sy[SC_THREADS], ss[SC_THREADS];
     const int ng = ngood ? *ngood : n;
     const int tiles = (ng + SC_THREADS - 1) / SC_THREADS;
-    if ((int)blockIdx.x >= tiles) return;
+    if ((int)blockIdx.x >= tiles || (int)blockIdx.y >= tiles) return;
     const int a = blockIdx.x * SC_THREADS + threadIdx.x;
     float ax = 0.f, ay = 0.f, as = 0.f;
     if (a < ng) {
@@ -149,7 +155,8 @@ __global__ __launch_bounds__(SC_THREADS) void nms_kernel(
         ax = p.x; ay = p.y; as = score[f];
     }
     bool is_max = true;
-    for (int t0 = 0; t0 < ng; t0 += SC_THREADS) {
+    for (int tb = blockIdx.y; tb < tiles; tb += gridDim.y) {
+        const int t0 = tb * SC_THREADS;
         const int b = t0 + threadIdx.x;
         if (b < ng) {
             const int f2 = good ? good[b] : b;
@@ -166,30 +173,38 @@ __global__ __launch_bounds__(SC_THREADS) void nms_kernel(
         }
         __syncthreads();
     }
-    const bool kp = a < ng && is_max;
-    if (a < ng) keep[a] = kp;
+    if (a < ng && !is_max) suppressed[a] = 1;
+}
+
+// suppressed -> keep flags (in place) and kept-per-tile counts
+__global__ __launch_bounds__(SC_THREADS) void nms_count_kernel(uint8_t *__restrict__ flags, int n,
+                                                               const int *__restrict__ ngood,
+                                                               int *__restrict__ tile_counts)
+{
+    const int ng = ngood ? *ngood : n;
+    const int tiles = (ng + SC_THREADS - 1) / SC_THREADS;
+    if ((int)blockIdx.x >= tiles) return;
+    const int a = blockIdx.x * SC_THREADS + threadIdx.x;
+    const bool kp = a < ng && !flags[a];
+    if (a < ng) flags[a] = kp;
     tile_count(kp, tile_counts);
 }
 
-// Features.cpp:783: sort by score descending; equal scores keep their input order
+// Features.cpp:783: sort by score descending; equal scores keep their input order.  Partial
+// ranks over the same tiling of the pair space, summed with integer atomics.
 __global__ __launch_bounds__(SC_THREADS) void rank_kernel(
-    const float2 *__restrict__ xy, const float *__restrict__ score, const int *__restrict__ kept,
-    const int *__restrict__ nkept, float2 *__restrict__ xy_out, float *__restrict__ score_out,
-    int32_t *__restrict__ index_out)
+    const float *__restrict__ score, const int *__restrict__ kept, const int *__restrict__ nkept,
+    int *__restrict__ rank_out)
 {
     __shared__ float ss[SC_THREADS];
     const int nk = *nkept;
     const int tiles = (nk + SC_THREADS - 1) / SC_THREADS;
-    if ((int)blockIdx.x >= tiles) return;
+    if ((int)blockIdx.x >= tiles || (int)blockIdx.y >= tiles) return;
     const int a = blockIdx.x * SC_THREADS + threadIdx.x;
-    int f = 0;
-    float as = 0.f;
-    if (a < nk) {
-        f = kept[a];
-        as = score[f];
-    }
+    const float as = a < nk ? score[kept[a]] : 0.f;
     int rank = 0;
-    for (int t0 = 0; t0 < nk; t0 += SC_THREADS) {
+    for (int tb = blockIdx.y; tb < tiles; tb += gridDim.y) {
+        const int t0 = tb * SC_THREADS;
         const int b = t0 + threadIdx.x;
         if (b < nk) ss[threadIdx.x] = score[kept[b]];
         __syncthreads();
@@ -197,11 +212,20 @@ __global__ __launch_bounds__(SC_THREADS) void rank_kernel(
         for (int j = 0; j < cnt; ++j) rank += (ss[j] > as) || (ss[j] == as && t0 + j < a);
         __syncthreads();
     }
-    if (a < nk) {
-        xy_out[rank] = xy[f];
-        score_out[rank] = as;
-        index_out[rank] = f;
-    }
+    if (a < nk && rank) atomicAdd(rank_out + a, rank);
+}
+
+__global__ __launch_bounds__(SC_THREADS) void rank_scatter_kernel(
+    const float2 *__restrict__ xy, const float *__restrict__ score, const int *__restrict__ kept,
+    const int *__restrict__ nkept, const int *__restrict__ rank, float2 *__restrict__ xy_out,
+    float *__restrict__ score_out, int32_t *__restrict__ index_out)
+{
+    const int a = blockIdx.x * SC_THREADS + threadIdx.x;
+    if (a >= *nkept) return;
+    const int f = kept[a], r = rank[a];
+    xy_out[r] = xy[f];
+    score_out[r] = score[f];
+    index_out[r] = f;
 }
 
 }  // namespace
@@ -215,28 +239,33 @@ int stx_launch_score_cluster(stx_ctx *ctx, const uint8_t *d_gx, const uint8_t *d
     if (n <= 0) return (int)hipMemsetAsync(d_count, 0, sizeof(int), st);
     const int tiles = (n + SC_THREADS - 1) / SC_THREADS;
     int err;
-    // [score n][good n][kept n][tile_counts tiles][counts 4][keep n bytes]
-    const size_t words = (size_t)3 * n + tiles + 4;
+    // [score n][good n][kept n][rank n][tile_counts tiles][counts 4][flags n bytes]
+    const size_t words = (size_t)4 * n + tiles + 4;
     int *ws = (int *)stx_workspace(ctx, STX_SLOT_SCORE, sizeof(int) * words + (size_t)n, &err);
     if (!ws) return err;
     float *score = reinterpret_cast<float *>(ws);
     int *good = ws + n;
     int *kept = good + n;
-    int *tile_counts = kept + n;
+    int *rank = kept + n;
+    int *tile_counts = rank + n;
     int *counts = tile_counts + tiles;  // [0] = ngood
-    uint8_t *keep = reinterpret_cast<uint8_t *>(counts + 4);
+    uint8_t *flags = reinterpret_cast<uint8_t *>(counts + 4);
     Kernel3x3 k;
     for (int i = 0; i < 9; ++i) k.w[i] = kernel3x3[i];
     const float2 *xy = reinterpret_cast<const float2 *>(d_xy);
+    const dim3 pairs(tiles, tiles < SC_SLICES ? tiles : SC_SLICES);
     hipLaunchKernelGGL(score_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, d_gx, d_gy, w, h, stride, xy, n, k,
-                       score_threshold, score, keep, tile_counts);
-    hipLaunchKernelGGL(compact_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, keep, tile_counts,
+                       score_threshold, score, flags, tile_counts);
+    hipLaunchKernelGGL(compact_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, flags, tile_counts,
                        (const int *)nullptr, n, (const int *)nullptr, good, counts);
-    hipLaunchKernelGGL(nms_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, xy, score, good, n, counts, cluster_dist,
-                       keep, tile_counts);
-    hipLaunchKernelGGL(compact_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, keep, tile_counts, good, n, counts,
+    STX_HIP(hipMemsetAsync(flags, 0, (size_t)n, st));
+    STX_HIP(hipMemsetAsync(rank, 0, sizeof(int) * (size_t)n, st));
+    hipLaunchKernelGGL(nms_kernel, pairs, dim3(SC_THREADS), 0, st, xy, score, good, n, counts, cluster_dist, flags);
+    hipLaunchKernelGGL(nms_count_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, flags, n, counts, tile_counts);
+    hipLaunchKernelGGL(compact_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, flags, tile_counts, good, n, counts,
                        kept, d_count);
-    hipLaunchKernelGGL(rank_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, xy, score, kept, d_count,
+    hipLaunchKernelGGL(rank_kernel, pairs, dim3(SC_THREADS), 0, st, score, kept, d_count, rank);
+    hipLaunchKernelGGL(rank_scatter_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, xy, score, kept, d_count, rank,
                        reinterpret_cast<float2 *>(d_xy_out), d_score_out, d_index_out);
     return (int)hipGetLastError();
 }
@@ -253,8 +282,12 @@ int stx_launch_cluster(stx_ctx *ctx, const float *d_xy, const float *d_score, in
     int *tile_counts = (int *)stx_workspace(ctx, STX_SLOT_SCORE, sizeof(int) * (size_t)tiles + (size_t)n, &err);
     if (!tile_counts) return err;
     uint8_t *keep = reinterpret_cast<uint8_t *>(tile_counts + tiles);
-    hipLaunchKernelGGL(nms_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, reinterpret_cast<const float2 *>(d_xy),
-                       d_score, (const int *)nullptr, n, (const int *)nullptr, window, keep, tile_counts);
+    STX_HIP(hipMemsetAsync(keep, 0, (size_t)n, st));
+    hipLaunchKernelGGL(nms_kernel, dim3(tiles, tiles < SC_SLICES ? tiles : SC_SLICES), dim3(SC_THREADS), 0, st,
+                       reinterpret_cast<const float2 *>(d_xy), d_score, (const int *)nullptr, n,
+                       (const int *)nullptr, window, keep);
+    hipLaunchKernelGGL(nms_count_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, keep, n, (const int *)nullptr,
+                       tile_counts);
     hipLaunchKernelGGL(compact_kernel, dim3(tiles), dim3(SC_THREADS), 0, st, keep, tile_counts,
                        (const int *)nullptr, n, (const int *)nullptr, d_index_out, d_count);
     return (int)hipGetLastError();
