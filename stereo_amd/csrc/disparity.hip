@@ -255,6 +255,26 @@ __device__ __forceinline__ unsigned sad_u32_0(unsigned a, unsigned b)
     asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// sum of the four byte-wise |a - b| (+ c), and the same sum shifted into the upper half-word:
+// with one pixel per dword (bytes 1..3 zero) these add |a - b| to the low or the high 16 bits
+__device__ __forceinline__ unsigned sad_u8(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_sad_u8 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned sad_hi_u8(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_sad_hi_u8 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned sad_u8_0(unsigned a, unsigned b)
+{
+    unsigned r;
+    asm("v_sad_u8 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ unsigned min3_u32(unsigned a, unsigned b, unsigned c)
 {
     unsigned r;
@@ -278,13 +298,32 @@ __device__ __forceinline__ unsigned sq_u24(unsigned t)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// One ds_read_b128.  The empty asm keeps the 16-byte load whole: without it the
-// element extracts are scalarised and re-merged as ds_read2_b32 pairs.
-__device__ __forceinline__ u32x4 lds_read_b128(const u32x4 *p)
+// Five or six ds_read_b128 issued back to back, then ONE wait.  The empty asm keeps the
+// 16-byte loads whole (without it the element extracts are scalarised and re-merged as
+// ds_read2_b32 pairs); it takes all the loaded vectors at once, so the compiler may issue
+// every read before the single s_waitcnt it needs (one asm per load made it wait after each
+// read: six serialised LDS round trips per phase, right behind the row barrier where all 16
+// waves of the workgroup stall together).
+__device__ __forceinline__ void lds_read_5(const u32x4 *p, unsigned (&v)[20])
 {
-    u32x4 t = *p;
-    asm volatile("" : "+v"(t));
-    return t;
+    u32x4 t0 = p[0], t1 = p[1], t2 = p[2], t3 = p[3], t4 = p[4];
+    asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4));
+    v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w;
+    v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+    v[8] = t2.x; v[9] = t2.y; v[10] = t2.z; v[11] = t2.w;
+    v[12] = t3.x; v[13] = t3.y; v[14] = t3.z; v[15] = t3.w;
+    v[16] = t4.x; v[17] = t4.y; v[18] = t4.z; v[19] = t4.w;
+}
+__device__ __forceinline__ void lds_read_1_5(const u32x4 *q, const u32x4 *p, unsigned (&l)[4], unsigned (&v)[20])
+{
+    u32x4 tl = q[0], t0 = p[0], t1 = p[1], t2 = p[2], t3 = p[3], t4 = p[4];
+    asm volatile("" : "+v"(tl), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4));
+    l[0] = tl.x; l[1] = tl.y; l[2] = tl.z; l[3] = tl.w;
+    v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w;
+    v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+    v[8] = t2.x; v[9] = t2.y; v[10] = t2.z; v[11] = t2.w;
+    v[12] = t3.x; v[13] = t3.y; v[14] = t3.z; v[15] = t3.w;
+    v[16] = t4.x; v[17] = t4.y; v[18] = t4.z; v[19] = t4.w;
 }
 
 __device__ __forceinline__ unsigned from_left(unsigned v)
@@ -323,12 +362,20 @@ struct BandArgs {
 template <int R, bool SSD>
 __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs a)
 {
-    constexpr unsigned SH = SSD ? 8u : BAND_SH;      // key = cost << SH | code
-    constexpr unsigned PSH = SSD ? 4u : BAND_SH;     // pixel pre-shift in the ring
+    constexpr int WIN = 2 * R + 1;
+    // PK (SAD windows): a window cost is below 2^15, so the column sums of two disparities, d
+    // and d + 8, share one register as half-words (v_sad_u8 / v_sad_hi_u8 add a tap to either
+    // half); the row-leaving subtraction and the whole horizontal slide then run once per PAIR
+    // of disparities.  key = cost << 16 | (65535 - d).  Disparities past D start from PK_PAST per
+    // column, which lifts their costs above every valid one (PK_PAST > 255 * WIN) without
+    // leaving the half-word (WIN * (PK_PAST + 255 * WIN) < 65536).
+    constexpr bool PK = !SSD && R > 0;
+    constexpr unsigned PK_PAST = 3584u;
+    constexpr unsigned SH = PK ? 16u : SSD ? 8u : BAND_SH;  // key = cost << SH | code
+    constexpr unsigned PSH = PK ? 0u : SSD ? 4u : BAND_SH;  // pixel pre-shift in the ring
     constexpr unsigned LOW = (1u << SH) - 1;
     constexpr unsigned PAST_D = SSD ? BAND_MASKED : BAND_PAST_D;
-    constexpr unsigned INIT = SSD ? 0x7FFFFFFFu : BAND_INIT;
-    constexpr int WIN = 2 * R + 1;
+    constexpr unsigned INIT = PK ? (((unsigned)(WIN * WIN * 255 + 1) << 16) - 1u) : SSD ? 0x7FFFFFFFu : BAND_INIT;
     constexpr int HL = (R + 3) / 4;  // halo lanes on each side of the tile
     constexpr int TILE_OUT = BAND_COLS - 8 * HL;
     static_assert(WIN + 2 <= BAND_RING, "ring too small");
@@ -399,8 +446,19 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     // window holds exactly one such column, the sliding add/subtract of rows never touches
     // the constant, so each window cost comes out as (cost << 12) + (4095 - d) with no extra
     // instruction.  Disparities past D (partial last block) carry BAND_PAST_D the same way.
-    unsigned V[BAND_ND][4];
-    {
+    unsigned V[PK ? BAND_ND / 2 : BAND_ND][4];
+    unsigned code_lo[PK ? BAND_ND / 2 : 1], code_hi[PK ? BAND_ND / 2 : 1];
+    if constexpr (PK) {
+#pragma unroll
+        for (int pp = 0; pp < BAND_ND / 2; ++pp) {
+            const int dlo = dB + pp, dhi = dB + pp + BAND_ND / 2;
+            code_lo[pp] = LOW - (unsigned)dlo;
+            code_hi[pp] = LOW - (unsigned)dhi;
+            const unsigned init = (dlo < a.D ? 0u : PK_PAST) | ((dhi < a.D ? 0u : PK_PAST) << 16);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) V[pp][c] = init;
+        }
+    } else {
         bool carrier[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) carrier[c] = ((x0 + 4 * lane + c + 1024 * WIN) % WIN) == 0;
@@ -424,15 +482,17 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
         // ---- add the row entering the window --------------------------------
         if (active) {
             const int slot = (ys + 64) & (BAND_RING - 1);
-            const u32x4 lv4 = lds_read_b128(Lrow4 + slot * (BAND_COLS / 4) + lane);
-            const u32x4 *rp = Rrow4 + slot * rw4 + roff4;
-            unsigned rv[20];
+            unsigned rv[20], lv[4];
+            lds_read_1_5(Lrow4 + slot * (BAND_COLS / 4) + lane, Rrow4 + slot * rw4 + roff4, lv, rv);
+            if constexpr (PK) {
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const u32x4 t = lds_read_b128(rp + j);
-                rv[4 * j] = t.x; rv[4 * j + 1] = t.y; rv[4 * j + 2] = t.z; rv[4 * j + 3] = t.w;
-            }
-            const unsigned lv[4] = {lv4.x, lv4.y, lv4.z, lv4.w};
+                for (int pp = 0; pp < BAND_ND / 2; ++pp)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const unsigned t = sad_u8(rv[16 + c - pp], lv[c], V[pp][c]);
+                        V[pp][c] = sad_hi_u8(rv[16 + c - pp - BAND_ND / 2], lv[c], t);
+                    }
+            } else
 #pragma unroll
             for (int dd = 0; dd < BAND_ND; ++dd)
 #pragma unroll
@@ -451,15 +511,17 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
         // ---- subtract the row leaving the window ----------------------------
         if (active && R > 0 && ys - WIN >= ys0) {
             const int slot = (ys - WIN + 64) & (BAND_RING - 1);
-            const u32x4 lv4 = lds_read_b128(Lrow4 + slot * (BAND_COLS / 4) + lane);
-            const u32x4 *rp = Rrow4 + slot * rw4 + roff4;
-            unsigned rv[20];
+            unsigned rv[20], lv[4];
+            lds_read_1_5(Lrow4 + slot * (BAND_COLS / 4) + lane, Rrow4 + slot * rw4 + roff4, lv, rv);
+            if constexpr (PK) {
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const u32x4 t = lds_read_b128(rp + j);
-                rv[4 * j] = t.x; rv[4 * j + 1] = t.y; rv[4 * j + 2] = t.z; rv[4 * j + 3] = t.w;
-            }
-            const unsigned lv[4] = {lv4.x, lv4.y, lv4.z, lv4.w};
+                for (int pp = 0; pp < BAND_ND / 2; ++pp)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const unsigned t = sad_u8_0(rv[16 + c - pp], lv[c]);
+                        V[pp][c] -= sad_hi_u8(rv[16 + c - pp - BAND_ND / 2], lv[c], t);
+                    }
+            } else
 #pragma unroll
             for (int dd = 0; dd < BAND_ND; ++dd)
 #pragma unroll
@@ -473,17 +535,12 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
         const int y = ys - R;
         if (active && y >= yb) {
             const int slot = (y + 64) & (BAND_RING - 1);
-            const u32x4 *mp = Mrow4 + slot * rw4 + roff4;
             unsigned mv[20];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const u32x4 t = lds_read_b128(mp + j);
-                mv[4 * j] = t.x; mv[4 * j + 1] = t.y; mv[4 * j + 2] = t.z; mv[4 * j + 3] = t.w;
-            }
+            lds_read_5(Mrow4 + slot * rw4 + roff4, mv);
             unsigned m[4] = {~0u, ~0u, ~0u, ~0u};
             unsigned pend[4];
 #pragma unroll
-            for (int dd = 0; dd < BAND_ND; ++dd) {
+            for (int dd = 0; dd < (PK ? BAND_ND / 2 : BAND_ND); ++dd) {
                 unsigned cost[4];
                 if (R == 0) {
 #pragma unroll
@@ -517,6 +574,15 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
                         }
                     }
                 }
+                if constexpr (PK) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        // the two half-word costs become two keys; mask word: 0 or BAND_MASKED
+                        const unsigned klo = ((cost[c] << 16) | code_lo[dd]) | mv[16 + c - dd];
+                        const unsigned khi = ((cost[c] & 0xFFFF0000u) | code_hi[dd]) | mv[16 + c - dd - BAND_ND / 2];
+                        m[c] = min3_u32(m[c], klo, khi);
+                    }
+                } else
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     // mask word: 0 or BAND_MASKED
