@@ -39,7 +39,32 @@ def special_descriptors(seed, n1, n2):
     return d1, s1, d2, s2
 
 
+def grad_images(seed, h, w):
+    """Stand-ins for the CV_8U GaussianBlur + Sobel outputs of Features.cpp:684-690."""
+    rng = np.random.RandomState(seed)
+    gx = np.clip(rng.randn(h, w) * 60, 0, 255).astype(np.uint8)
+    gy = np.clip(rng.randn(h, w) * 60, 0, 255).astype(np.uint8)
+    return gx, gy
+
+
+def features():
+    # N3: FAST -> score + NMS -> descriptors on one small image, ClusterFeatures on its corners
+    img = synth.texture(9, 96, 128)
+    gx, gy = grad_images(3, 96, 128)
+    xy = o.fast_features(img)
+    kern = o.gaussian_kernel(3, 1.0)
+    sxy, ssc, sidx = o.score_and_cluster(gx, gy, xy, kern, 700.0, 2.0)
+    ang, desc = o.sift_descriptors(gx, gy, sxy)
+    rng = np.random.RandomState(4)
+    cscore = rng.randint(0, 30, len(xy)).astype(np.float32)
+    cidx = o.cluster_features(xy, cscore, 20)
+    np.savez_compressed(os.path.join(HERE, "f_128x96.npz"), img=img, gx=gx, gy=gy, fast_xy=xy, kernel=kern,
+                        score_xy=sxy, score=ssc, score_index=sidx, angle=ang, desc=desc,
+                        cluster_score=cscore, cluster_index=cidx)
+
+
 def main():
+    features()
     # D, reference mode
     l, r = synth.rectified_pair(1234, 48, 64, 16)
     np.savez_compressed(os.path.join(HERE, "d_ref_64x48.npz"), img0=l, img1=r,

@@ -905,3 +905,18 @@ def test_feature_chain_fast_score_describe_match(ctx, oracle):
     assert len(matches) == len(acc)
     for (a, b), i in zip(matches, acc):
         assert a.p == tuple(map(float, lists[0][1][i])) and b.p == tuple(map(float, lists[1][1][want[0][i]]))
+
+
+def test_feature_golden_vectors_gpu(ctx):
+    """The committed feature-chain vectors (tests/golden/f_128x96.npz) through the C ABI."""
+    g = np.load(os.path.join(GOLD, "f_128x96.npz"))
+    xy, cnt = ctx.fast_detect(g["img"])
+    assert cnt == len(g["fast_xy"]) and xy.tobytes() == g["fast_xy"].tobytes()
+    assert ctx.gaussian_kernel().tobytes() == g["kernel"].tobytes()
+    sxy, ssc, sidx = ctx.score_cluster(g["gx"], g["gy"], xy, g["kernel"], 700.0, 2.0)
+    assert sxy.tobytes() == g["score_xy"].tobytes() and ssc.tobytes() == g["score"].tobytes()
+    assert sidx.tolist() == g["score_index"].tolist()
+    ang, desc = ctx.sift_descriptors(g["gx"], g["gy"], sxy)
+    assert ang.tobytes() == g["angle"].tobytes()
+    assert np.array_equal(desc.view(np.uint32), g["desc"].view(np.uint32))
+    assert ctx.cluster_features(xy, g["cluster_score"], 20).tolist() == g["cluster_index"].tolist()

@@ -496,3 +496,19 @@ def test_sift_descriptor_matches_second_restatement_bit_for_bit(oracle):
         a2, d2 = _sift_np(gx, gy, x, y, 0.5, k9, k4)
         assert np.float32(ang[i]).tobytes() == np.float32(a2).tobytes()
         assert desc[i].tobytes() == d2.tobytes(), (i, np.abs(desc[i] - d2).max())
+
+
+def test_feature_golden_vectors(oracle):
+    """tests/golden/f_128x96.npz (made by tests/golden/make_golden.py): the oracle today still
+    produces the committed FAST / score + NMS / descriptor / ClusterFeatures outputs."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f_128x96.npz"))
+    assert oracle.fast_features(g["img"]).tobytes() == g["fast_xy"].tobytes()
+    assert oracle.gaussian_kernel(3, 1.0).tobytes() == g["kernel"].tobytes()
+    sxy, ssc, sidx = oracle.score_and_cluster(g["gx"], g["gy"], g["fast_xy"], g["kernel"], 700.0, 2.0)
+    assert sxy.tobytes() == g["score_xy"].tobytes() and ssc.tobytes() == g["score"].tobytes()
+    assert sidx.tolist() == g["score_index"].tolist() and len(sidx) > 5
+    ang, desc = oracle.sift_descriptors(g["gx"], g["gy"], sxy)
+    assert ang.tobytes() == g["angle"].tobytes()
+    assert np.array_equal(desc.view(np.uint32), g["desc"].view(np.uint32))
+    assert oracle.cluster_features(g["fast_xy"], g["cluster_score"], 20).tolist() == g["cluster_index"].tolist()
