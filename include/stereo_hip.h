@@ -261,6 +261,43 @@ int stx_sift_descriptors_dev(stx_ctx *ctx, const uint8_t *d_gx, const uint8_t *d
 /* CreateGaussianKernel (stereo/Features.cpp:20-34) on the host: out[r * size + c]. */
 int stx_gaussian_kernel(int size, float sigma, float *out);
 
+/* ---- RANSAC hypothesis scoring (between M and R) -------------------------------
+ * Replaces the pair loop of FindFundamentalMatrixWithRANSAC (stereo/Stereography.cpp:226-238;
+ * decl Stereography.h:29; call main.cpp:220) for a batch of n_hyp hypotheses over the same n
+ * pairs: per pair ReprojectionError (:163-182) -> Triangulate (:383-443; decl Stereography.h:31)
+ * -> LindstromOptimisation (:354-381), then localInliers and the running avgError (:232-236).
+ * The draws, FindFundamentalMatrix and the singular value decompositions stay with the caller
+ * (Eigen BDCSVD in the reference); each hypothesis is one record of STX_HYP_FLOATS floats:
+ *   [0..8]   E, row-major, as DecomposeEssentialMatrix at :225 leaves it (it scales E in place, :318)
+ *   [9..17]  R, [18..20] t of that call (its 4th and 3rd outputs as named at :225)
+ *   [21..29] R, [30..32] t of the decomposition inside Triangulate (:398): decompose a COPY of
+ *            the scaled E once more -- ReprojectionError takes E by value, so every pair sees the
+ *            same matrices
+ *   [33]     0 if that inner decomposition failed (Triangulate then returns false), else nonzero
+ *   [34..35] unused
+ * K1, K2: the camera matrices (stereo.img1.K, stereo.img2.K), row-major; their inverses and
+ * R.inverse() are taken as Eigen's 3x3 inverse does (stx_invert_homography).  p1, p2: n (x, y)
+ * float pairs (m.first.p, m.second.p).  exclude (may be NULL): n_hyp x 8 positions, in the
+ * pair list, of each hypothesis's chosen eight, which the reference erases before the loop
+ * (:205-211).  threshold: FUNDAMENTAL_REPROJECTION_ERROR_THRESHOLD (70, Stereography.h:11).
+ * Outputs: inliers[h] = localInliers; err_sum[h] = avgError before the division at :240, summed
+ * in pair order; errors (may be NULL; n_hyp x n): every pair's error, 1000 where Triangulate
+ * fails, -1 for excluded pairs; depths (may be NULL; n_hyp x n x 2): Triangulate's depth0,
+ * depth1 (NaN where it fails or the pair is excluded).  hyp, K1, K2, exclude are always host
+ * arrays.  fp32 throughout, dot products summed left to right without contraction; parity with
+ * Eigen's evaluation order is unpinned.  Host pointers. */
+#define STX_HYP_FLOATS 36
+int stx_ransac_score(stx_ctx *ctx, const float *hyp, int n_hyp, const float K1[9], const float K2[9],
+                     const float *p1, const float *p2, int n, const int32_t *exclude, float threshold,
+                     int32_t *inliers, float *err_sum, float *errors, float *depths);
+
+/* Device-resident form: d_* are device pointers (d_errors, d_depths may be NULL); asynchronous
+ * after the hypothesis records have been uploaded. */
+int stx_ransac_score_dev(stx_ctx *ctx, const float *hyp, int n_hyp, const float K1[9], const float K2[9],
+                         const float *d_p1, const float *d_p2, int n, const int32_t *exclude,
+                         float threshold, int32_t *d_inliers, float *d_err_sum, float *d_errors,
+                         float *d_depths);
+
 /* ---- R+D fused on the device ---------------------------------------------
  * main.cpp:362-380 in one call: both images are rectified into zero-initialised
  * destinations of the source size (RectifyImage twice, Stereography.cpp:596-631) and the

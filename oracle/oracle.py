@@ -185,3 +185,24 @@ def sift_descriptors(gx, gy, xy, angle=None):
     lib().oracle_sift_descriptors(_p(gx), _p(gy), w, h, C.c_size_t(max(w, 1)), _p(xy), n, _p(k9), _p(k4),
                                   _p(ang), _p(desc))
     return ang[:n].copy(), desc[:n].copy()
+
+
+HYP_FLOATS = 36
+
+
+def ransac_score(hyp, K1, K2, p1, p2, exclude=None, threshold=70.0):
+    """(inliers [H], err_sum [H], errors [H,n], depths [H,n,2]) -- oracle_ransac_score."""
+    hyp = np.ascontiguousarray(hyp, np.float32).reshape(-1, HYP_FLOATS)
+    k1 = np.ascontiguousarray(K1, np.float32).reshape(9)
+    k2 = np.ascontiguousarray(K2, np.float32).reshape(9)
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    nh, n = hyp.shape[0], p1.shape[0]
+    ex = None if exclude is None else np.ascontiguousarray(exclude, np.int32).reshape(nh, 8)
+    inl = np.zeros(max(nh, 1), np.int32)
+    esum = np.zeros(max(nh, 1), np.float32)
+    errors = np.zeros((nh, n), np.float32)
+    depths = np.zeros((nh, n, 2), np.float32)
+    lib().oracle_ransac_score(_p(hyp), nh, _p(k1), _p(k2), _p(p1), _p(p2), n, _p(ex) if ex is not None else None,
+                              C.c_float(threshold), _p(inl), _p(esum), _p(errors), _p(depths))
+    return inl[:nh].copy(), esum[:nh].copy(), errors, depths

@@ -700,3 +700,158 @@ void oracle_sift_descriptors(const uint8_t *gx, const uint8_t *gy, int w, int h,
         oracle_normalise128(vec); /* :929 */
     }
 }
+
+/* ---- RANSAC hypothesis scoring --------------------------------- */
+
+/* row r of a row-major 3x3 times a vector, summed left to right */
+static float row_dot3(const float *m, int r, const float v[3])
+{
+    float s = m[r * 3] * v[0];
+    s = s + m[r * 3 + 1] * v[1];
+    s = s + m[r * 3 + 2] * v[2];
+    return s;
+}
+
+/* column c of a row-major 3x3 times a vector (a row vector times the matrix) */
+static float col_dot3(const float *m, int c, const float v[3])
+{
+    float s = m[c] * v[0];
+    s = s + m[3 + c] * v[1];
+    s = s + m[6 + c] * v[2];
+    return s;
+}
+
+void oracle_lindstrom(float x[3], float xp[3], const float E[9])
+{
+    /* Etilde = S E S^T is E's upper-left 2x2 (:360); S only selects rows */
+    const float e00 = E[0], e01 = E[1], e10 = E[3], e11 = E[4];
+    float n0 = row_dot3(E, 0, xp), n1 = row_dot3(E, 1, xp);  /* n = S E x' (:362) */
+    float m0 = col_dot3(E, 0, x), m1 = col_dot3(E, 1, x);    /* n' = S E^T x (:363) */
+    /* a = n^T Etilde n' (:366): the row vector n^T Etilde first */
+    float r0 = n0 * e00 + n1 * e10, r1 = n0 * e01 + n1 * e11;
+    float a = r0 * m0 + r1 * m1;
+    float b = 0.5f * ((n0 * n0 + n1 * n1) + (m0 * m0 + m1 * m1)); /* :367 */
+    /* c = x^T E x' (:368): the row vector x^T E first */
+    float q[3] = {col_dot3(E, 0, x), col_dot3(E, 1, x), col_dot3(E, 2, x)};
+    float c = q[0] * xp[0];
+    c = c + q[1] * xp[1];
+    c = c + q[2] * xp[2];
+    float d = sqrtf(b * b - a * c);
+    float lambda = c / (b + d);
+    float xd0 = lambda * n0, xd1 = lambda * n1;    /* x_delta (:371) */
+    float pd0 = lambda * m0, pd1 = lambda * m1;    /* xprime_delta (:372) */
+    n0 = n0 - (e00 * pd0 + e01 * pd1);             /* :373 */
+    n1 = n1 - (e10 * pd0 + e11 * pd1);
+    m0 = m0 - (e00 * xd0 + e01 * xd1);             /* :375, Etilde again (not its transpose) */
+    m1 = m1 - (e10 * xd0 + e11 * xd1);
+    float sx = (xd0 * n0 + xd1 * n1) / (n0 * n0 + n1 * n1);   /* :377 */
+    xd0 = sx * n0;
+    xd1 = sx * n1;
+    float sp = (pd0 * m0 + pd1 * m1) / (m0 * m0 + m1 * m1);   /* :378 */
+    pd0 = sp * m0;
+    pd1 = sp * m1;
+    x[0] = x[0] - xd0;  /* :379, S^T pads the third row with 0 */
+    x[1] = x[1] - xd1;
+    x[2] = x[2] - 0.0f;
+    xp[0] = xp[0] - pd0;
+    xp[1] = xp[1] - pd1;
+    xp[2] = xp[2] - 0.0f;
+}
+
+static float dot3(const float a[3], const float b[3])
+{
+    float s = a[0] * b[0];
+    s = s + a[1] * b[1];
+    s = s + a[2] * b[2];
+    return s;
+}
+
+int oracle_triangulate(float *depth0, float *depth1, float x[3], float xp[3], const float E[9],
+                       const float R[9], const float t[3], int decomp_ok)
+{
+    oracle_lindstrom(x, xp, E);
+    if (!decomp_ok) return 0;  /* :398-401 */
+    float nx[3] = {x[0] / x[2], x[1] / x[2], x[2] / x[2]};        /* :403 */
+    float v[3] = {xp[0] / xp[2], xp[1] / xp[2], xp[2] / xp[2]};   /* :404, :406 */
+    float u[3] = {row_dot3(R, 0, nx), row_dot3(R, 1, nx), row_dot3(R, 2, nx)};  /* :405 */
+    float un = sqrtf(dot3(u, u)), vn = sqrtf(dot3(v, v));
+    for (int i = 0; i < 3; ++i) {
+        u[i] = u[i] / un;  /* :408 */
+        v[i] = v[i] / vn;  /* :409 */
+    }
+    float a = dot3(u, t), b = dot3(u, u), c = dot3(u, v), d = dot3(v, t), e = dot3(v, v);
+    float g = c * c - b * e;
+    if ((double)fabsf(g) < 1e-9) return 0;  /* :418 */
+    float d0, d1;
+    if ((double)fabsf(c) < 1e-9) {  /* :422 */
+        d1 = (a * c - b * d) / (c * c - b * e);
+        d0 = (c * d1 - a) / b;
+    } else {
+        d0 = (a * e - c * d) / (c * c - b * e);
+        d1 = (a + b * d0) / c;
+    }
+    /* :433-437 (the 3-D point) has no effect on the outputs */
+    *depth0 = d0;
+    *depth1 = d1;
+    return 1;
+}
+
+float oracle_reprojection_error(const float hyp[ORACLE_HYP_FLOATS], const float K1inv[9],
+                                const float K2inv[9], const float K2[9], const float p1[2],
+                                const float p2[2], float *d0_out, float *d1_out)
+{
+    const float *E = hyp, *R = hyp + 9, *t = hyp + 18, *Rt = hyp + 21, *tt = hyp + 30;
+    const float P1[3] = {p1[0], p1[1], 1.0f}, P2[3] = {p2[0], p2[1], 1.0f};  /* :228-229 */
+    float point1[3] = {row_dot3(K1inv, 0, P1), row_dot3(K1inv, 1, P1), row_dot3(K1inv, 2, P1)};  /* :167 */
+    float point2[3] = {row_dot3(K2inv, 0, P2), row_dot3(K2inv, 1, P2), row_dot3(K2inv, 2, P2)};  /* :168 */
+    float d0 = NAN, d1 = NAN;
+    int ok = oracle_triangulate(&d0, &d1, point1, point2, E, Rt, tt, hyp[33] != 0.0f);
+    if (d0_out) *d0_out = ok ? d0 : NAN;
+    if (d1_out) *d1_out = ok ? d1 : NAN;
+    if (!ok) return 1000.0f;  /* :172 */
+    float Rinv[9];
+    oracle_invert3x3(R, Rinv);  /* R.inverse(), :175 */
+    float s[3] = {point1[0] * d1, point1[1] * d1, point1[2] * d1};
+    float tp[3];
+    for (int i = 0; i < 3; ++i) tp[i] = row_dot3(Rinv, i, s) - row_dot3(Rinv, i, t);  /* :175 */
+    float z = tp[2];
+    for (int i = 0; i < 3; ++i) tp[i] = tp[i] / z;  /* :176 */
+    float w[3] = {row_dot3(K2, 0, tp), row_dot3(K2, 1, tp), row_dot3(K2, 2, tp)};  /* :177 */
+    float df[3] = {w[0] - P1[0], w[1] - P1[1], w[2] - P1[2]};
+    return sqrtf(dot3(df, df));  /* :179 */
+}
+
+void oracle_ransac_score(const float *hyp, int H, const float K1[9], const float K2[9], const float *p1,
+                         const float *p2, int n, const int32_t *exclude, float threshold,
+                         int32_t *inliers, float *err_sum, float *errors, float *depths)
+{
+    float K1inv[9], K2inv[9];
+    oracle_invert3x3(K1, K1inv);
+    oracle_invert3x3(K2, K2inv);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int h = 0; h < H; ++h) {
+        const float *hy = hyp + (size_t)h * ORACLE_HYP_FLOATS;
+        int count = 0;
+        float sum = 0.0f;
+        for (int i = 0; i < n; ++i) {
+            int skip = 0;
+            if (exclude)
+                for (int k = 0; k < 8; ++k) skip |= exclude[(size_t)h * 8 + k] == i;
+            float d0 = NAN, d1 = NAN, err = -1.0f;
+            if (!skip) {
+                err = oracle_reprojection_error(hy, K1inv, K2inv, K2, p1 + 2 * (size_t)i, p2 + 2 * (size_t)i, &d0, &d1);
+                if (err < threshold) {  /* :232-236 */
+                    count++;
+                    sum += err;
+                }
+            }
+            if (errors) errors[(size_t)h * n + i] = err;
+            if (depths) {
+                depths[((size_t)h * n + i) * 2] = d0;
+                depths[((size_t)h * n + i) * 2 + 1] = d1;
+            }
+        }
+        inliers[h] = count;
+        err_sum[h] = sum;
+    }
+}

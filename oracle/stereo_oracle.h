@@ -158,6 +158,46 @@ void oracle_sift_descriptors(const uint8_t *gx, const uint8_t *gy, int w, int h,
                              const float *xy, int n, const float k9[81], const float k4[16],
                              float *angle, float *desc);
 
+/* ---- RANSAC hypothesis scoring ---------------------------------
+ * PARITY UNPINNED against Eigen: the reference evaluates these 3x3 / 2x2 expressions through
+ * Eigen templates whose summation order is not visible in its own source; here every dot
+ * product is summed left to right in fp32, without contraction.  The singular value
+ * decompositions (DecomposeEssentialMatrix, Stereography.cpp:301-353) are NOT restated: their
+ * outputs are inputs here, one record per hypothesis:
+ *   hyp[0..8]   E, row-major, as the call at :225 leaves it (scaled by its first singular value)
+ *   hyp[9..17]  R and hyp[18..20] t of that call (its fourth and third arguments, :225)
+ *   hyp[21..29] R and hyp[30..32] t of the decomposition inside Triangulate (:398) -- the same
+ *               for every pair, since ReprojectionError takes E by value (:163)
+ *   hyp[33]     0 if that inner decomposition failed (Triangulate returns false), else nonzero
+ *   hyp[34..35] unused */
+#define ORACLE_HYP_FLOATS 36
+
+/* LindstromOptimisation, stereo/Stereography.cpp:354-381; x and xp are updated in place. */
+void oracle_lindstrom(float x[3], float xp[3], const float E[9]);
+
+/* Triangulate, stereo/Stereography.cpp:383-443, with the outcome of the decomposition at :398
+ * passed in.  x, xp are updated in place (they are references in the reference); returns 0 where
+ * the reference returns false. */
+int oracle_triangulate(float *d0, float *d1, float x[3], float xp[3], const float E[9],
+                       const float R[9], const float t[3], int decomp_ok);
+
+/* ReprojectionError, stereo/Stereography.cpp:163-182, for one pair under one hypothesis.
+ * K1inv, K2inv are oracle_invert3x3 of the camera matrices (K.inverse(), :167-168).  d0/d1
+ * (optional) receive Triangulate's depths, NaN where it fails. */
+float oracle_reprojection_error(const float hyp[ORACLE_HYP_FLOATS], const float K1inv[9],
+                                const float K2inv[9], const float K2[9], const float p1[2],
+                                const float p2[2], float *d0, float *d1);
+
+/* The pair loop of FindFundamentalMatrixWithRANSAC, stereo/Stereography.cpp:226-238, for H
+ * hypotheses over the same n pairs.  exclude (optional): H x 8 positions of each hypothesis's
+ * chosen eight in the pair list, which the reference erases before the loop (:205-211).
+ * inliers[h] = localInliers, err_sum[h] = avgError before the division at :240 (summed in pair
+ * order).  errors (optional, H x n): every pair's error, -1 for the excluded ones; depths
+ * (optional, H x n x 2): Triangulate's d0, d1. */
+void oracle_ransac_score(const float *hyp, int H, const float K1[9], const float K2[9], const float *p1,
+                         const float *p2, int n, const int32_t *exclude, float threshold,
+                         int32_t *inliers, float *err_sum, float *errors, float *depths);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,10 @@ PROTOTYPES = {
     "stx_cluster_features_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "stx_sift_descriptors": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_int, _vp, _vp]),
     "stx_sift_descriptors_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_int, _vp, _vp]),
+    "stx_ransac_score": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_float, _vp, _vp, _vp,
+                                   _vp]),
+    "stx_ransac_score_dev": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_float, _vp, _vp,
+                                       _vp, _vp]),
     "stx_gaussian_kernel": (C.c_int, [C.c_int, C.c_float, _f32p]),
     "stx_rectify_disparity_u8": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_size_t, _f32p, _f32p,
                                            C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp, _vp,

@@ -29,6 +29,10 @@ FAST_THRESHOLD = 30  # stereo/Features.h:13
 ST_THRESH = 700.0    # stereo/Features.h:14
 NMS_WINDOW = 2       # stereo/Features.h:16
 ST_WINDOW = 3        # stereo/Features.h:24
+FUNDAMENTAL_REPROJECTION_ERROR_THRESHOLD = 70  # stereo/Stereography.h:11
+MIN_NUM_INLIERS = 20                           # stereo/Stereography.h:12
+FUNDAMENTAL_RANSAC_ITERATIONS = 200            # stereo/Stereography.h:13
+HYP_FLOATS = 36      # STX_HYP_FLOATS, include/stereo_hip.h
 
 MATCH_FAILED, MATCH_SCORE, MATCH_RATIO, MATCH_ACCEPTED = 0, 1, 2, 3
 COST_SAD, COST_SSD = 0, 1
@@ -265,6 +269,62 @@ class Context:
                                               float(score_threshold), float(cluster_dist), xy_out.data_ptr(),
                                               score_out.data_ptr(), index_out.data_ptr(), count.data_ptr()),
               "stx_score_cluster_dev")
+
+    # -- hypothesis scoring ---------------------------------------------------
+    def ransac_score(self, hyp, K1, K2, p1, p2, exclude=None, threshold=FUNDAMENTAL_REPROJECTION_ERROR_THRESHOLD,
+                     want_errors=False, want_depths=False):
+        """The pair loop of FindFundamentalMatrixWithRANSAC (stereo/Stereography.cpp:226-238) for
+        every hypothesis record in `hyp` ([H, 36], layout in include/stereo_hip.h).  Returns
+        (inliers [H] int32, err_sum [H] float32[, errors [H,n]][, depths [H,n,2]])."""
+        hyp = np.ascontiguousarray(hyp, np.float32).reshape(-1, HYP_FLOATS)
+        k1 = np.ascontiguousarray(K1, np.float32).reshape(9)
+        k2 = np.ascontiguousarray(K2, np.float32).reshape(9)
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        if p1.shape != p2.shape:
+            raise ValueError("p1 and p2 must have the same length")
+        nh, n = hyp.shape[0], p1.shape[0]
+        ex = None
+        if exclude is not None:
+            ex = np.ascontiguousarray(exclude, np.int32).reshape(-1, 8)
+            if ex.shape[0] != nh:
+                raise ValueError("exclude must hold eight positions per hypothesis")
+        inl = np.zeros(max(nh, 1), np.int32)
+        esum = np.zeros(max(nh, 1), np.float32)
+        errors = np.zeros((nh, n), np.float32) if want_errors else None
+        depths = np.zeros((nh, n, 2), np.float32) if want_depths else None
+        check(self._lib.stx_ransac_score(self._h, _ptr(hyp), nh, _ptr(k1), _ptr(k2), _ptr(p1), _ptr(p2), n,
+                                         _ptr(ex) if ex is not None else None, float(threshold), _ptr(inl),
+                                         _ptr(esum), _ptr(errors) if want_errors else None,
+                                         _ptr(depths) if want_depths else None), "stx_ransac_score")
+        out = (inl[:nh], esum[:nh])
+        if want_errors:
+            out += (errors,)
+        if want_depths:
+            out += (depths,)
+        return out
+
+    def ransac_score_dev(self, hyp, K1, K2, p1, p2, exclude, threshold, inliers, err_sum, errors=None, depths=None):
+        """Device tensors: p1, p2 [n,2] float32, inliers [H] int32, err_sum [H] float32, errors
+        [H,n] / depths [H,n,2] float32 or None; hyp [H,36], K1, K2, exclude [H,8] host arrays."""
+        hyp = np.ascontiguousarray(hyp, np.float32).reshape(-1, HYP_FLOATS)
+        k1 = np.ascontiguousarray(K1, np.float32).reshape(9)
+        k2 = np.ascontiguousarray(K2, np.float32).reshape(9)
+        ex = None if exclude is None else np.ascontiguousarray(exclude, np.int32).reshape(-1, 8)
+        if ex is not None and ex.shape[0] != hyp.shape[0]:
+            raise ValueError("exclude must hold eight positions per hypothesis")
+        n = int(p1.shape[0])
+        for t, shape, name in ((p1, (n, 2), "p1"), (p2, (n, 2), "p2"), (inliers, (hyp.shape[0],), "inliers"),
+                               (err_sum, (hyp.shape[0],), "err_sum"), (errors, (hyp.shape[0], n), "errors"),
+                               (depths, (hyp.shape[0], n, 2), "depths")):
+            if t is not None and (tuple(t.shape) != shape or not t.is_contiguous() or t.element_size() != 4):
+                raise ValueError("%s must be a contiguous 4-byte tensor of shape %s" % (name, shape))
+        check(self._lib.stx_ransac_score_dev(self._h, _ptr(hyp), hyp.shape[0], _ptr(k1), _ptr(k2), p1.data_ptr(),
+                                             p2.data_ptr(), int(p1.shape[0]), _ptr(ex) if ex is not None else None,
+                                             float(threshold), inliers.data_ptr(), err_sum.data_ptr(),
+                                             errors.data_ptr() if errors is not None else None,
+                                             depths.data_ptr() if depths is not None else None),
+              "stx_ransac_score_dev")
 
     # -- D ------------------------------------------------------------------
     def disparity(self, img0, img1, win=1, max_disp=0, cost_mode=COST_SAD, out_dtype=np.uint8):

@@ -1,0 +1,251 @@
+// RANSAC hypothesis scoring for gfx950: the pair loop of FindFundamentalMatrixWithRANSAC
+// (stereo/Stereography.cpp:226-238) for every hypothesis of a batch at once -- per (hypothesis,
+// pair) ReprojectionError (:163-182) -> Triangulate (:383-443) -> LindstromOptimisation
+// (:354-381), then per hypothesis the inlier count and the in-order sum of the inlier errors.
+//
+// What stays on the host: drawing the eight pairs, FindFundamentalMatrix and the singular value
+// decompositions of DecomposeEssentialMatrix (:301-353) -- 3x3 / 8x9 Eigen BDCSVD calls, a few
+// hundred per image pair.  Their outputs come in as one record per hypothesis (stereo_hip.h).
+// ReprojectionError takes E by value (:163), so the decomposition inside Triangulate (:398) sees
+// the same matrix for every pair of a hypothesis: it is a per-hypothesis input as well.
+//
+// Arithmetic: fp32, every multiply, add, divide and sqrt its own correctly rounded operation
+// (-ffp-contract=off), dot products summed left to right -- the order an unoptimised build of
+// the reference's Eigen expressions evaluates them in.  The error sum of a hypothesis is taken
+// in pair order by a serial chain (fp32 addition does not reassociate), one wave per hypothesis.
+//
+// Bound: compute (about 30 IEEE divisions and square roots per evaluation); 16 B of pair data
+// in and 4 B of error out per evaluation.
+#include "stx_internal.h"
+
+#include <math.h>
+#include <vector>
+
+namespace {
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_REC = 48;  // floats per device record
+
+// device record: E[9] Rinv[9] Rinv*t[3] R'[9] t'[3] ok exclude[8] pad
+struct Cams {
+    float k1inv[9], k2inv[9], k2[9];
+};
+
+__device__ __forceinline__ float row_dot3(const float *m, int r, float v0, float v1, float v2)
+{
+    float s = m[r * 3] * v0;
+    s = s + m[r * 3 + 1] * v1;
+    s = s + m[r * 3 + 2] * v2;
+    return s;
+}
+
+__device__ __forceinline__ float col_dot3(const float *m, int c, float v0, float v1, float v2)
+{
+    float s = m[c] * v0;
+    s = s + m[3 + c] * v1;
+    s = s + m[6 + c] * v2;
+    return s;
+}
+
+__device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, float b1, float b2)
+{
+    float s = a0 * b0;
+    s = s + a1 * b1;
+    s = s + a2 * b2;
+    return s;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void ransac_error_kernel(
+    const float *__restrict__ rec, Cams cams, const float2 *__restrict__ p1, const float2 *__restrict__ p2, int n,
+    float *__restrict__ errors, float2 *__restrict__ depths)
+{
+    __shared__ float r[RS_REC];
+    const int h = blockIdx.y;
+    if (threadIdx.x < RS_REC) r[threadIdx.x] = rec[(size_t)h * RS_REC + threadIdx.x];
+    __syncthreads();
+    const int i = blockIdx.x * RS_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float *E = r, *Rinv = r + 9, *Rinvt = r + 18, *Rt = r + 21, *tt = r + 30;
+    const int *excl = reinterpret_cast<const int *>(r + 34);
+    bool skip = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) skip |= excl[k] == i;
+    const size_t o = (size_t)h * n + i;
+    const float nanv = __builtin_nanf("");
+    if (skip) {
+        errors[o] = -1.0f;
+        if (depths) depths[o] = make_float2(nanv, nanv);
+        return;
+    }
+    const float2 a1 = p1[i], a2 = p2[i];
+    // :167-168
+    float x0 = row_dot3(cams.k1inv, 0, a1.x, a1.y, 1.0f), x1 = row_dot3(cams.k1inv, 1, a1.x, a1.y, 1.0f),
+          x2 = row_dot3(cams.k1inv, 2, a1.x, a1.y, 1.0f);
+    float y0 = row_dot3(cams.k2inv, 0, a2.x, a2.y, 1.0f), y1 = row_dot3(cams.k2inv, 1, a2.x, a2.y, 1.0f),
+          y2 = row_dot3(cams.k2inv, 2, a2.x, a2.y, 1.0f);
+
+    // ---- LindstromOptimisation, :354-381 ------------------------------------
+    {
+        const float e00 = E[0], e01 = E[1], e10 = E[3], e11 = E[4];
+        float n0 = row_dot3(E, 0, y0, y1, y2), n1 = row_dot3(E, 1, y0, y1, y2);
+        const float q0 = col_dot3(E, 0, x0, x1, x2), q1 = col_dot3(E, 1, x0, x1, x2), q2 = col_dot3(E, 2, x0, x1, x2);
+        float m0 = q0, m1 = q1;
+        const float r0 = n0 * e00 + n1 * e10, r1 = n0 * e01 + n1 * e11;
+        const float a = r0 * m0 + r1 * m1;
+        const float b = 0.5f * ((n0 * n0 + n1 * n1) + (m0 * m0 + m1 * m1));
+        const float c = dot3(q0, q1, q2, y0, y1, y2);
+        const float d = sqrtf(b * b - a * c);
+        const float lambda = c / (b + d);
+        float xd0 = lambda * n0, xd1 = lambda * n1;
+        float pd0 = lambda * m0, pd1 = lambda * m1;
+        n0 = n0 - (e00 * pd0 + e01 * pd1);
+        n1 = n1 - (e10 * pd0 + e11 * pd1);
+        m0 = m0 - (e00 * xd0 + e01 * xd1);
+        m1 = m1 - (e10 * xd0 + e11 * xd1);
+        const float sx = (xd0 * n0 + xd1 * n1) / (n0 * n0 + n1 * n1);
+        xd0 = sx * n0;
+        xd1 = sx * n1;
+        const float sp = (pd0 * m0 + pd1 * m1) / (m0 * m0 + m1 * m1);
+        pd0 = sp * m0;
+        pd1 = sp * m1;
+        x0 = x0 - xd0;
+        x1 = x1 - xd1;
+        y0 = y0 - pd0;
+        y1 = y1 - pd1;
+    }
+
+    // ---- Triangulate, :398-431 ------------------------------------------------
+    bool ok = r[33] != 0.0f;
+    float d0 = nanv, d1 = nanv;
+    if (ok) {
+        const float nx0 = x0 / x2, nx1 = x1 / x2, nx2 = x2 / x2;
+        float v0 = y0 / y2, v1 = y1 / y2, v2 = y2 / y2;
+        float u0 = row_dot3(Rt, 0, nx0, nx1, nx2), u1 = row_dot3(Rt, 1, nx0, nx1, nx2),
+              u2 = row_dot3(Rt, 2, nx0, nx1, nx2);
+        const float un = sqrtf(dot3(u0, u1, u2, u0, u1, u2)), vn = sqrtf(dot3(v0, v1, v2, v0, v1, v2));
+        u0 = u0 / un;
+        u1 = u1 / un;
+        u2 = u2 / un;
+        v0 = v0 / vn;
+        v1 = v1 / vn;
+        v2 = v2 / vn;
+        const float a = dot3(u0, u1, u2, tt[0], tt[1], tt[2]), b = dot3(u0, u1, u2, u0, u1, u2),
+                    c = dot3(u0, u1, u2, v0, v1, v2), d = dot3(v0, v1, v2, tt[0], tt[1], tt[2]),
+                    e = dot3(v0, v1, v2, v0, v1, v2);
+        const float g = c * c - b * e;
+        if ((double)fabsf(g) < 1e-9) {  // :418
+            ok = false;
+        } else if ((double)fabsf(c) < 1e-9) {  // :422
+            d1 = (a * c - b * d) / (c * c - b * e);
+            d0 = (c * d1 - a) / b;
+        } else {
+            d0 = (a * e - c * d) / (c * c - b * e);
+            d1 = (a + b * d0) / c;
+        }
+    }
+    if (depths) depths[o] = ok ? make_float2(d0, d1) : make_float2(nanv, nanv);
+    if (!ok) {
+        errors[o] = 1000.0f;  // :172
+        return;
+    }
+
+    // ---- ReprojectionError, :175-179 ----------------------------------------
+    const float s0 = x0 * d1, s1 = x1 * d1, s2 = x2 * d1;
+    float t0 = row_dot3(Rinv, 0, s0, s1, s2) - Rinvt[0];
+    float t1 = row_dot3(Rinv, 1, s0, s1, s2) - Rinvt[1];
+    float t2 = row_dot3(Rinv, 2, s0, s1, s2) - Rinvt[2];
+    const float z = t2;
+    t0 = t0 / z;
+    t1 = t1 / z;
+    t2 = t2 / z;
+    const float w0 = row_dot3(cams.k2, 0, t0, t1, t2) - a1.x, w1 = row_dot3(cams.k2, 1, t0, t1, t2) - a1.y,
+                w2 = row_dot3(cams.k2, 2, t0, t1, t2) - 1.0f;
+    errors[o] = sqrtf(dot3(w0, w1, w2, w0, w1, w2));
+}
+
+// One wave per hypothesis: localInliers and the running avgError of :232-236, the sum taken in
+// pair order.  An error that is not an inlier contributes +0, which leaves the (non-negative)
+// running sum unchanged, so the chain needs no branches; chunks without inliers are skipped.
+__global__ __launch_bounds__(64) void ransac_reduce_kernel(const float *__restrict__ errors, int n, float threshold,
+                                                           int32_t *__restrict__ inliers,
+                                                           float *__restrict__ err_sum)
+{
+    const int h = blockIdx.x, lane = threadIdx.x;
+    const float *e = errors + (size_t)h * n;
+    float sum = 0.0f;
+    int count = 0;
+    float next = lane < n ? e[lane] : -1.0f;
+    for (int base = 0; base < n; base += 64) {
+        const float cur = next;
+        const int j = base + 64 + lane;
+        next = j < n ? e[j] : -1.0f;
+        const bool in = cur >= 0.0f && cur < threshold;
+        const unsigned long long mask = __ballot(in);
+        if (mask == 0) continue;
+        count += __popcll(mask);
+        const float v = in ? cur : 0.0f;
+#pragma unroll
+        for (int l = 0; l < 64; ++l)
+            sum = sum + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+    }
+    if (lane == 0) {
+        inliers[h] = count;
+        err_sum[h] = sum;
+    }
+}
+
+float host_row_dot3(const float *m, int r, const float v[3])
+{
+    volatile float a = m[r * 3] * v[0], b = m[r * 3 + 1] * v[1], c = m[r * 3 + 2] * v[2];
+    volatile float s = a + b;
+    return s + c;
+}
+
+}  // namespace
+
+int stx_launch_ransac_score(stx_ctx *ctx, const float *hyp, int n_hyp, const float K1[9], const float K2[9],
+                            const float *d_p1, const float *d_p2, int n, const int32_t *exclude, float threshold,
+                            int32_t *d_inliers, float *d_err_sum, float *d_errors, float *d_depths)
+{
+    if (n_hyp <= 0) return STX_OK;
+    int err;
+    // [records n_hyp*RS_REC][errors n_hyp*n when the caller brings none]
+    const size_t rec_bytes = sizeof(float) * RS_REC * (size_t)n_hyp;
+    const size_t err_bytes = d_errors ? 0 : sizeof(float) * (size_t)n_hyp * (size_t)(n > 0 ? n : 1);
+    float *d_rec = (float *)stx_workspace(ctx, STX_SLOT_RANSAC, rec_bytes + err_bytes, &err);
+    if (!d_rec) return err;
+    if (!d_errors) d_errors = d_rec + RS_REC * (size_t)n_hyp;
+
+    Cams cams;
+    int rc = stx_invert_homography(K1, cams.k1inv);  // K1.inverse(), :167
+    if (rc) return rc;
+    rc = stx_invert_homography(K2, cams.k2inv);  // :168
+    if (rc) return rc;
+    for (int k = 0; k < 9; ++k) cams.k2[k] = K2[k];
+    std::vector<float> rec((size_t)RS_REC * n_hyp, 0.0f);
+    for (int hh = 0; hh < n_hyp; ++hh) {
+        const float *src = hyp + (size_t)hh * STX_HYP_FLOATS;
+        float *dst = rec.data() + (size_t)hh * RS_REC;
+        for (int k = 0; k < 9; ++k) dst[k] = src[k];
+        rc = stx_invert_homography(src + 9, dst + 9);  // R.inverse(), :175
+        if (rc) return rc;
+        for (int k = 0; k < 3; ++k) dst[18 + k] = host_row_dot3(dst + 9, k, src + 18);  // R.inverse() * t
+        for (int k = 0; k < 12; ++k) dst[21 + k] = src[21 + k];
+        dst[33] = src[33];
+        int32_t *ex = reinterpret_cast<int32_t *>(dst + 34);
+        for (int k = 0; k < 8; ++k) ex[k] = exclude ? exclude[(size_t)hh * 8 + k] : -1;
+    }
+    STX_HIP(hipMemcpyAsync(d_rec, rec.data(), rec_bytes, hipMemcpyHostToDevice, ctx->stream));
+    // the records were staged from pageable memory; wait so `rec` may go out of scope
+    STX_HIP(hipStreamSynchronize(ctx->stream));
+    if (n > 0) {
+        const dim3 grid((unsigned)((n + RS_THREADS - 1) / RS_THREADS), (unsigned)n_hyp);
+        hipLaunchKernelGGL(ransac_error_kernel, grid, dim3(RS_THREADS), 0, ctx->stream, d_rec, cams,
+                           reinterpret_cast<const float2 *>(d_p1), reinterpret_cast<const float2 *>(d_p2), n,
+                           d_errors, reinterpret_cast<float2 *>(d_depths));
+        STX_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(ransac_reduce_kernel, dim3((unsigned)n_hyp), dim3(64), 0, ctx->stream, d_errors, n, threshold,
+                       d_inliers, d_err_sum);
+    return (int)hipGetLastError();
+}

@@ -671,3 +671,59 @@ extern "C" int stx_sift_descriptors(stx_ctx *ctx, const uint8_t *gx, const uint8
     STX_HIP(hipStreamSynchronize(s));
     return STX_OK;
 }
+
+// ------------------------------------------------------ hypothesis scoring --
+
+static int check_ransac_args(stx_ctx *ctx, const float *hyp, int n_hyp, const float *K1, const float *K2,
+                             const float *p1, const float *p2, int n, const int32_t *inliers, const float *err_sum)
+{
+    if (!ctx || n_hyp < 0 || n < 0 || n_hyp > 65535) return STX_ERR_INVALID_ARG;
+    if (n_hyp > 0 && (!hyp || !K1 || !K2 || !inliers || !err_sum)) return STX_ERR_INVALID_ARG;
+    if (n_hyp > 0 && n > 0 && (!p1 || !p2)) return STX_ERR_INVALID_ARG;
+    return STX_OK;
+}
+
+extern "C" int stx_ransac_score_dev(stx_ctx *ctx, const float *hyp, int n_hyp, const float K1[9],
+                                    const float K2[9], const float *d_p1, const float *d_p2, int n,
+                                    const int32_t *exclude, float threshold, int32_t *d_inliers,
+                                    float *d_err_sum, float *d_errors, float *d_depths)
+{
+    int rc = check_ransac_args(ctx, hyp, n_hyp, K1, K2, d_p1, d_p2, n, d_inliers, d_err_sum);
+    if (rc) return rc;
+    STX_HIP(hipSetDevice(ctx->device));
+    return stx_launch_ransac_score(ctx, hyp, n_hyp, K1, K2, d_p1, d_p2, n, exclude, threshold, d_inliers,
+                                   d_err_sum, d_errors, d_depths);
+}
+
+extern "C" int stx_ransac_score(stx_ctx *ctx, const float *hyp, int n_hyp, const float K1[9], const float K2[9],
+                                const float *p1, const float *p2, int n, const int32_t *exclude,
+                                float threshold, int32_t *inliers, float *err_sum, float *errors, float *depths)
+{
+    int rc = check_ransac_args(ctx, hyp, n_hyp, K1, K2, p1, p2, n, inliers, err_sum);
+    if (rc) return rc;
+    if (n_hyp == 0) return STX_OK;
+    STX_HIP(hipSetDevice(ctx->device));
+    int err;
+    hipStream_t s = ctx->stream;
+    const size_t np = (size_t)n, nh = (size_t)n_hyp, cells = nh * np;
+    // [p1 n*2][p2 n*2][err_sum H][inliers H][errors H*n][depths H*n*2]
+    const size_t floats = 4 * np + 2 * nh + (errors ? cells : 0) + (depths ? 2 * cells : 0);
+    float *base = (float *)stx_workspace(ctx, STX_SLOT_SCORE_IO, sizeof(float) * floats, &err);
+    if (!base) return err;
+    float *dp1 = base, *dp2 = base + 2 * np, *dsum = base + 4 * np;
+    int32_t *dinl = reinterpret_cast<int32_t *>(dsum + nh);
+    float *derr = errors ? dsum + 2 * nh : nullptr;
+    float *ddep = depths ? dsum + 2 * nh + (errors ? cells : 0) : nullptr;
+    if (n > 0) {
+        STX_HIP(hipMemcpyAsync(dp1, p1, sizeof(float) * 2 * np, hipMemcpyHostToDevice, s));
+        STX_HIP(hipMemcpyAsync(dp2, p2, sizeof(float) * 2 * np, hipMemcpyHostToDevice, s));
+    }
+    rc = stx_launch_ransac_score(ctx, hyp, n_hyp, K1, K2, dp1, dp2, n, exclude, threshold, dinl, dsum, derr, ddep);
+    if (rc) return rc;
+    STX_HIP(hipMemcpyAsync(inliers, dinl, sizeof(int32_t) * nh, hipMemcpyDeviceToHost, s));
+    STX_HIP(hipMemcpyAsync(err_sum, dsum, sizeof(float) * nh, hipMemcpyDeviceToHost, s));
+    if (errors && cells) STX_HIP(hipMemcpyAsync(errors, derr, sizeof(float) * cells, hipMemcpyDeviceToHost, s));
+    if (depths && cells) STX_HIP(hipMemcpyAsync(depths, ddep, sizeof(float) * 2 * cells, hipMemcpyDeviceToHost, s));
+    STX_HIP(hipStreamSynchronize(s));
+    return STX_OK;
+}

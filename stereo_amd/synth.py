@@ -120,3 +120,31 @@ def homography(seed, w, h, deg_y=2.0, deg_x=0.5):
     Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
     Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
     return (K @ (Ry @ Rx) @ np.linalg.inv(K)).astype(np.float32)
+
+
+def two_view_matches(seed, n, outlier_frac=0.3, noise=0.5, w=2880, h=1988):
+    """Matched positions of n scene points seen by two cameras a baseline apart (config 5's
+    "RANSAC-fed rectification" input): (K1, K2, p1 [n,2], p2 [n,2], F) float32.  A fraction of
+    the pairs are mismatches (uniform positions in the second image)."""
+    rng = np.random.RandomState(seed)
+    f = 0.9 * w
+    k1 = np.array([[f, 0, w / 2.0], [0, f, h / 2.0], [0, 0, 1]], np.float64)
+    k2 = np.array([[f * 1.01, 0, w / 2.0 + 7], [0, f * 1.01, h / 2.0 - 4], [0, 0, 1]], np.float64)
+    ay, ax = np.deg2rad(2.0), np.deg2rad(-0.7)
+    ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    r = ry @ rx
+    t = np.array([-0.4, 0.02, 0.03])
+    x = np.stack([rng.uniform(-2.5, 2.5, n), rng.uniform(-1.7, 1.7, n), rng.uniform(4, 12, n)], axis=1)
+    a = (k1 @ x.T).T
+    b = (k2 @ (r @ x.T + t[:, None])).T
+    p1 = a[:, :2] / a[:, 2:] + rng.normal(0, noise, (n, 2))
+    p2 = b[:, :2] / b[:, 2:] + rng.normal(0, noise, (n, 2))
+    bad = rng.rand(n) < outlier_frac
+    p2[bad] = np.stack([rng.uniform(0, w, bad.sum()), rng.uniform(0, h, bad.sum())], axis=1)
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    fm = np.linalg.inv(k2).T @ (tx @ r) @ np.linalg.inv(k1)
+    fm = fm / fm[2, 2]
+    # (the products above are transposed views: force C order, [n,2] rows of (x, y))
+    c = np.ascontiguousarray
+    return c(k1, np.float32), c(k2, np.float32), c(p1, np.float32), c(p2, np.float32), c(fm, np.float32)

@@ -920,3 +920,124 @@ def test_feature_golden_vectors_gpu(ctx):
     assert ang.tobytes() == g["angle"].tobytes()
     assert np.array_equal(desc.view(np.uint32), g["desc"].view(np.uint32))
     assert ctx.cluster_features(xy, g["cluster_score"], 20).tolist() == g["cluster_index"].tolist()
+
+
+# ---------------------------------------------------- N2: hypothesis scoring ------
+
+def _same_f32(a, b):
+    """Equal as fp32 values; NaN matches NaN (the two sides' default NaNs differ in sign bit)."""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return a.shape == b.shape and bool(((a == b) | (np.isnan(a) & np.isnan(b))).all())
+
+
+def _hypotheses(p1, p2, k1, k2, fm, count, seed):
+    from stereo_amd import ransac
+    rng = ransac.msvc_rand(seed)
+    recs, excl = [ransac.hypothesis_record(fm, k1, k2)], [ransac.draw_eight(len(p1), rng)]
+    while len(recs) < count:
+        ch = ransac.draw_eight(len(p1), rng)
+        ok, f8 = ransac.find_fundamental_matrix(p1[ch], p2[ch])
+        rec = ransac.hypothesis_record(f8, k1, k2) if ok else None
+        if rec is not None:
+            recs.append(rec)
+            excl.append(ch)
+    return np.stack(recs), np.array(excl, np.int32)
+
+
+@pytest.mark.parametrize("n,nh", [(8, 1), (63, 3), (64, 2), (65, 5), (500, 40), (3001, 200)])
+def test_ransac_score_matches_oracle(ctx, oracle, n, nh):
+    from stereo_amd import synth
+    k1, k2, p1, p2, fm = synth.two_view_matches(100 + n, n)
+    recs, excl = _hypotheses(p1, p2, k1, k2, fm, nh, n)
+    for ex in (excl, None):
+        want = oracle.ransac_score(recs, k1, k2, p1, p2, ex)
+        got = ctx.ransac_score(recs, k1, k2, p1, p2, exclude=ex, want_errors=True, want_depths=True)
+        assert np.array_equal(got[0], want[0])
+        assert _same_f32(got[1], want[1]) and _same_f32(got[2], want[2]) and _same_f32(got[3], want[3])
+        lean = ctx.ransac_score(recs, k1, k2, p1, p2, exclude=ex)
+        assert np.array_equal(lean[0], want[0]) and _same_f32(lean[1], want[1])
+    if n >= 500:
+        assert want[0].max() > 20 and (want[0] == 0).sum() < nh   # inliers, sums and failures all occur
+
+
+def test_ransac_score_degenerate_records(ctx, oracle):
+    from stereo_amd import synth
+    k1, k2, p1, p2, fm = synth.two_view_matches(7, 130)
+    recs, _ = _hypotheses(p1, p2, k1, k2, fm, 6, 3)
+    recs[1, 33] = 0                      # inner decomposition failed: every error is 1000 (:172)
+    recs[2, :] = 0                       # all-zero matrices: 0/0 everywhere
+    recs[2, 33] = 1
+    recs[3, 0:9] *= np.float32(1e-30)    # denormal products
+    recs[4, 9:18] = 0                    # singular R: R.inverse() is all inf/NaN
+    recs[5, 30:33] = 0                   # t' = 0 -> a = d = 0 -> d0 = d1 = 0
+    p1[5] = p2[5] = 0
+    p1[6] = [np.inf, 1]
+    p2[7] = [np.nan, 2]
+    p1[8] = [3e38, -3e38]
+    for thr in (70.0, 2000.0, 0.0, np.inf):
+        want = oracle.ransac_score(recs, k1, k2, p1, p2, None, thr)
+        got = ctx.ransac_score(recs, k1, k2, p1, p2, threshold=thr, want_errors=True, want_depths=True)
+        assert np.array_equal(got[0], want[0]), thr
+        assert _same_f32(got[1], want[1]) and _same_f32(got[2], want[2]) and _same_f32(got[3], want[3])
+    assert (want[2][1] == 1000).all() and want[0][1] == 130   # threshold inf: every pair counts
+
+
+def test_ransac_score_empty_inputs(ctx):
+    k = np.eye(3, dtype=np.float32)
+    inl, tot = ctx.ransac_score(np.zeros((0, 36), np.float32), k, k, np.zeros((5, 2)), np.zeros((5, 2)))
+    assert len(inl) == 0 and len(tot) == 0
+    rec = np.zeros((3, 36), np.float32)
+    inl, tot, err, dep = ctx.ransac_score(rec, k, k, np.zeros((0, 2)), np.zeros((0, 2)), want_errors=True,
+                                          want_depths=True)
+    assert inl.tolist() == [0, 0, 0] and tot.tolist() == [0, 0, 0] and err.shape == (3, 0)
+    with pytest.raises(ValueError):
+        ctx.ransac_score(rec, k, k, np.zeros((4, 2)), np.zeros((5, 2)))
+    with pytest.raises(ValueError):
+        ctx.ransac_score(rec, k, k, np.zeros((4, 2)), np.zeros((4, 2)), exclude=np.zeros((2, 8), np.int32))
+
+
+def test_ransac_score_dev_full_size(ctx, oracle):
+    """Config 5's scale: 200 hypotheses x 200k pairs on device tensors, bit-exact against the oracle."""
+    import torch
+    from stereo_amd import synth
+    n, nh = 200_000, 200
+    k1, k2, p1, p2, fm = synth.two_view_matches(55, n)
+    recs, excl = _hypotheses(p1[:4000], p2[:4000], k1, k2, fm, nh, 8)
+    dev = torch.device("cuda", 0)
+    d1, d2 = torch.from_numpy(p1).to(dev), torch.from_numpy(p2).to(dev)
+    inl = torch.zeros(nh, dtype=torch.int32, device=dev)
+    tot = torch.zeros(nh, dtype=torch.float32, device=dev)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.ransac_score_dev(recs, k1, k2, d1, d2, excl, 70.0, inl, tot)
+        torch.cuda.synchronize()
+        want = oracle.ransac_score(recs, k1, k2, p1, p2, excl)
+        assert np.array_equal(inl.cpu().numpy(), want[0]) and _same_f32(tot.cpu().numpy(), want[1])
+        assert want[0].max() > 10000
+        # caller-owned error / depth tensors
+        err = torch.zeros((nh, n), dtype=torch.float32, device=dev)
+        dep = torch.zeros((nh, n, 2), dtype=torch.float32, device=dev)
+        ctx.ransac_score_dev(recs, k1, k2, d1, d2, excl, 70.0, inl, tot, err, dep)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_stream(0)
+    assert np.array_equal(inl.cpu().numpy(), want[0]) and _same_f32(tot.cpu().numpy(), want[1])
+    assert _same_f32(err.cpu().numpy(), want[2]) and _same_f32(dep.cpu().numpy(), want[3])
+
+
+def test_find_fundamental_matrix_with_ransac(ctx, oracle):
+    """The host loop around the kernel: same winner as the same loop scored by the oracle, and the
+    winner explains the true matches."""
+    from stereo_amd import ransac, synth
+    k1, k2, p1, p2, fm = synth.two_view_matches(21, 900, outlier_frac=0.25)
+    ok, f = ransac.FindFundamentalMatrixWithRANSAC(p1, p2, k1, k2, seed=4, ctx=ctx)
+
+    class OracleScorer:
+        def ransac_score(self, recs, a, b, q1, q2, exclude=None):
+            return oracle.ransac_score(recs, a, b, q1, q2, exclude)[:2]
+
+    ok2, f2 = ransac.FindFundamentalMatrixWithRANSAC(p1, p2, k1, k2, seed=4, ctx=OracleScorer())
+    assert ok == ok2 and ok
+    assert np.array_equal(f, f2)
+    ok3, f3 = ransac.FindFundamentalMatrixWithRANSAC(p1, p2, k1, k2, seed=5, ctx=ctx)
+    assert ok3 and not np.array_equal(f, f3)   # another seed draws other pairs

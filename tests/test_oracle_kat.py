@@ -512,3 +512,197 @@ def test_feature_golden_vectors(oracle):
     assert ang.tobytes() == g["angle"].tobytes()
     assert np.array_equal(desc.view(np.uint32), g["desc"].view(np.uint32))
     assert oracle.cluster_features(g["fast_xy"], g["cluster_score"], 20).tolist() == g["cluster_index"].tolist()
+
+
+# ------------------------------------------------- N2: hypothesis scoring ------
+
+def _skew(t):
+    return np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]], np.float64)
+
+
+def _geometry(seed=3, n=40):
+    """Exact two-view geometry X2 = R X1 + t and the rays of n points in both cameras."""
+    rng = np.random.RandomState(seed)
+    a = np.deg2rad(3.0)
+    r = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    t = np.array([-0.5, 0.03, 0.02])
+    x1 = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1, 1, n), rng.uniform(4, 9, n)], axis=1)
+    x2 = (r @ x1.T).T + t
+    return r, t, x1, x2
+
+
+def test_lindstrom_leaves_points_with_zero_residual(oracle):
+    # Stereography.cpp:368-372: c = x^T E x' = 0 -> lambda = 0 -> both corrections vanish.
+    # (The reference evaluates x^T E x' with x from the FIRST image, so the matrix that makes the
+    # residual vanish for exact rays is the transpose of [t]x R.)
+    import ctypes as C
+    r, t, x1, x2 = _geometry()
+    e = np.ascontiguousarray((_skew(t) @ r).T, np.float32)
+    for a, b in zip(x1, x2):
+        x = (a / a[2]).astype(np.float32)
+        xp = (b / b[2]).astype(np.float32)
+        x0, xp0 = x.copy(), xp.copy()
+        oracle.lib().oracle_lindstrom(C.c_void_p(x.ctypes.data), C.c_void_p(xp.ctypes.data),
+                                      C.c_void_p(e.ctypes.data))
+        assert np.allclose(x, x0, atol=2e-6) and np.allclose(xp, xp0, atol=2e-6)
+
+
+def test_triangulate_depths_are_ray_lengths(oracle):
+    # :403-431: u = R x / |R x|, v = x' / |x'|, t + d0 u = d1 v  ->  d0 = |X1|, d1 = |X2| for exact rays
+    import ctypes as C
+    r, t, x1, x2 = _geometry(5)
+    e = np.ascontiguousarray((_skew(t) @ r).T, np.float32)
+    rf, tf = r.astype(np.float32), t.astype(np.float32)
+    f = oracle.lib().oracle_triangulate
+    for a, b in zip(x1, x2):
+        x = (a / a[2] * 1.7).astype(np.float32)     # any scale of the ray: :403 divides by x(2)
+        xp = (b / b[2] * 0.6).astype(np.float32)
+        d0, d1 = C.c_float(0), C.c_float(0)
+        ok = f(C.byref(d0), C.byref(d1), C.c_void_p(x.ctypes.data), C.c_void_p(xp.ctypes.data),
+               C.c_void_p(e.ctypes.data), C.c_void_p(rf.ctypes.data), C.c_void_p(tf.ctypes.data), 1)
+        assert ok == 1
+        assert abs(d0.value - np.linalg.norm(a)) < 1e-3 * np.linalg.norm(a)
+        assert abs(d1.value - np.linalg.norm(b)) < 1e-3 * np.linalg.norm(b)
+        # a failed inner decomposition (:398-401) returns false after the Lindstrom step
+        assert f(C.byref(d0), C.byref(d1), C.c_void_p(x.ctypes.data), C.c_void_p(xp.ctypes.data),
+                 C.c_void_p(e.ctypes.data), C.c_void_p(rf.ctypes.data), C.c_void_p(tf.ctypes.data), 0) == 0
+
+
+def test_triangulate_parallel_rays_fail(oracle):
+    # :417-418: g = c*c - b*e = 0 for parallel unit rays -> false -> ReprojectionError returns 1000 (:172)
+    hyp = np.zeros(36, np.float32)
+    hyp[0:9] = np.ascontiguousarray((_skew([1, 0, 0]) @ np.eye(3)).T).reshape(9)
+    hyp[9:18] = hyp[21:30] = np.eye(3, dtype=np.float32).reshape(9)
+    hyp[18:21] = hyp[30:33] = [1, 0, 0]
+    hyp[33] = 1
+    k = np.eye(3, dtype=np.float32)
+    p = np.array([[0.25, -0.5]], np.float32)
+    inl, tot, err, dep = oracle.ransac_score(hyp[None], k, k, p, p, threshold=2000.0)
+    assert err[0, 0] == 1000.0 and inl[0] == 1 and tot[0] == 1000.0 and np.isnan(dep[0, 0]).all()
+
+
+def _reprojection_np(hyp, k1, k2, p1, p2):
+    """Second restatement of ReprojectionError / Triangulate / LindstromOptimisation, written
+    with the reference's matrix expressions (S, Etilde, transposes) in numpy float32."""
+    f = np.float32
+    e = hyp[0:9].reshape(3, 3)
+    r, t = hyp[9:18].reshape(3, 3), hyp[18:21]
+    rt, tt = hyp[21:30].reshape(3, 3), hyp[30:33]
+    s = np.array([[1, 0, 0], [0, 1, 0]], f)
+    x = np.linalg.inv(k1.astype(np.float64)).astype(f) @ np.array([p1[0], p1[1], 1], f)
+    xp = np.linalg.inv(k2.astype(np.float64)).astype(f) @ np.array([p2[0], p2[1], 1], f)
+    et = s @ e @ s.T
+    n = s @ e @ xp
+    npr = s @ e.T @ x
+    a = n @ et @ npr
+    b = f(0.5) * (n @ n + npr @ npr)
+    c = x @ e @ xp
+    with np.errstate(invalid="ignore"):
+        d = np.sqrt(f(b * b - a * c))
+    lam = c / (b + d)
+    xd, pd = lam * n, lam * npr
+    n = n - et @ pd
+    npr = npr - et @ xd
+    xd = (xd @ n) / (n @ n) * n
+    pd = (pd @ npr) / (npr @ npr) * npr
+    x = x - s.T @ xd
+    xp = xp - s.T @ pd
+    u = rt @ (x / x[2])
+    v = xp / xp[2]
+    u = u / np.linalg.norm(u)
+    v = v / np.linalg.norm(v)
+    a, b, c, d, ee = u @ tt, u @ u, u @ v, v @ tt, v @ v
+    g = c * c - b * ee
+    if abs(g) < 1e-9:
+        return 1000.0, np.nan, np.nan
+    if abs(c) < 1e-9:
+        d1 = (a * c - b * d) / g
+        d0 = (c * d1 - a) / b
+    else:
+        d0 = (a * ee - c * d) / g
+        d1 = (a + b * d0) / c
+    rinv = np.linalg.inv(r.astype(np.float64)).astype(f)
+    tp = rinv @ (x * d1) - rinv @ t
+    tp = tp / tp[2]
+    tp = k2 @ tp
+    return float(np.linalg.norm(tp - np.array([p1[0], p1[1], 1], f))), float(d0), float(d1)
+
+
+def test_ransac_score_matches_matrix_form_restatement(oracle):
+    from stereo_amd import ransac, synth
+    k1, k2, p1, p2, fm = synth.two_view_matches(11, 300)
+    rng = ransac.msvc_rand(7)
+    recs = [ransac.hypothesis_record(fm, k1, k2)]
+    for _ in range(6):
+        ch = ransac.draw_eight(len(p1), rng)
+        ok, f8 = ransac.find_fundamental_matrix(p1[ch], p2[ch])
+        assert ok
+        recs.append(ransac.hypothesis_record(f8, k1, k2))
+    recs = np.stack(recs)
+    inl, tot, err, dep = oracle.ransac_score(recs, k1, k2, p1, p2)
+    close = 0
+    for h in range(len(recs)):
+        for i in range(len(p1)):
+            want, d0, d1 = _reprojection_np(recs[h], k1, k2, p1[i], p2[i])
+            # the two differ only in summation order; ill-conditioned pairs (tiny g) are excused
+            if (np.isnan(want) and np.isnan(err[h, i])) or abs(err[h, i] - want) <= 2e-3 * max(1.0, abs(want)):
+                close += 1   # sqrt of a negative discriminant (:369) gives NaN in both
+    assert close >= 0.995 * err.size, (close, err.size)
+    # counts and in-order sums follow from the per-pair errors (:232-236)
+    for h in range(len(recs)):
+        acc, cnt = np.float32(0), 0
+        for v in err[h]:
+            if v < 70:
+                acc = np.float32(acc + v)
+                cnt += 1
+        assert cnt == inl[h] and acc == tot[h]
+    assert 10 < inl[0] < len(p1)
+
+
+def test_ransac_exclude_skips_the_chosen_eight(oracle):
+    from stereo_amd import ransac, synth
+    k1, k2, p1, p2, fm = synth.two_view_matches(12, 64)
+    rec = ransac.hypothesis_record(fm, k1, k2)[None]
+    ex = np.array([[0, 5, 9, 17, 33, 40, 62, 63]], np.int32)
+    inl_a, tot_a, err_a, _ = oracle.ransac_score(rec, k1, k2, p1, p2)
+    inl_b, tot_b, err_b, dep_b = oracle.ransac_score(rec, k1, k2, p1, p2, exclude=ex)
+    keep = np.ones(64, bool)
+    keep[ex[0]] = False
+    assert (err_b[0, ex[0]] == -1).all() and np.isnan(dep_b[0, ex[0]]).all()
+    assert np.array_equal(err_b[0, keep], err_a[0, keep])
+    assert inl_b[0] == inl_a[0] - (err_a[0, ex[0]] < 70).sum()
+
+
+def test_msvc_rand_known_sequence_and_draws():
+    from stereo_amd import ransac
+    g = ransac.msvc_rand(1)
+    assert [next(g) for _ in range(5)] == [41, 18467, 6334, 26500, 19169]   # the CRT's well-known start
+    # :205-211: each draw indexes the pairs still left
+    seq = iter([3, 3, 0, 6, 2, 1, 1, 0])
+    assert ransac.draw_eight(10, seq) == [3, 4, 0, 9, 5, 2, 6, 1]
+    ch = ransac.draw_eight(8, ransac.msvc_rand(9))
+    assert sorted(ch) == list(range(8))
+
+
+def test_select_hypothesis_follows_the_int_min_error():
+    from stereo_amd import ransac
+    # :191 minError is an int: 50.9 is stored as 50, so a later 50.5 does not replace it (:242)
+    inl = np.array([21, 25, 30, 20, 40])
+    tot = np.array([21 * 50.9, 25 * 50.5, 30 * 49.99, 20 * 1.0, 40 * 49.5], np.float32)
+    assert ransac.select_hypothesis(inl, tot) == 2        # 49.99 < 50 -> minError 49; 49.5 is not < 49
+    assert ransac.select_hypothesis(inl[:2], tot[:2]) == 0
+    assert ransac.select_hypothesis(inl[3:4], tot[3:4]) == -1   # needs MORE than 20 inliers
+    assert ransac.select_hypothesis(np.array([0]), np.array([0], np.float32)) == -1
+
+
+def test_find_fundamental_matrix_satisfies_the_epipolar_constraint():
+    from stereo_amd import ransac, synth
+    k1, k2, p1, p2, fm = synth.two_view_matches(13, 8, outlier_frac=0.0, noise=0.0)
+    ok, f8 = ransac.find_fundamental_matrix(p1, p2)
+    assert ok and f8[2, 2] == 1.0
+    a = np.hstack([p1, np.ones((8, 1), np.float32)]).astype(np.float64)
+    b = np.hstack([p2, np.ones((8, 1), np.float32)]).astype(np.float64)
+    res = np.einsum("ij,jk,ik->i", b, f8.astype(np.float64), a)   # y'^T F y, :117
+    scale = np.abs(f8).max() * 2880 * 2880
+    assert np.abs(res).max() < 1e-3 * scale
+    assert ransac.find_fundamental_matrix(p1[:7], p2[:7]) == (False, None)   # :79-82
