@@ -300,6 +300,33 @@ def main():
                         "of the %d surviving features" % nsurv,
             "ms": ms, "features_per_s": nsurv / (ms * 1e-3),
         }
+        # RANSAC hypothesis scoring (the step between matching and rectification in config 5)
+        from stereo_amd import ransac as rsc
+        rn, rh_ = 200_000, api.FUNDAMENTAL_RANSAC_ITERATIONS
+        rk1, rk2, rp1, rp2, rfm = synth.two_view_matches(77, rn)
+        rrng = rsc.msvc_rand(1)
+        recs, excl = [], []
+        while len(recs) < rh_:
+            ch = rsc.draw_eight(4000, rrng)
+            okf, f8 = rsc.find_fundamental_matrix(rp1[ch], rp2[ch])
+            rec = rsc.hypothesis_record(f8, rk1, rk2) if okf else None
+            if rec is not None:
+                recs.append(rec)
+                excl.append(ch)
+        recs, excl = np.stack(recs), np.array(excl, np.int32)
+        t_p1, t_p2 = torch.from_numpy(rp1).cuda(), torch.from_numpy(rp2).cuda()
+        r_inl = torch.zeros(rh_, dtype=torch.int32, device="cuda")
+        r_sum = torch.zeros(rh_, dtype=torch.float32, device="cuda")
+        ms = event_time_ms(torch, lambda: ctx.ransac_score_dev(recs, rk1, rk2, t_p1, t_p2, excl,
+                                                               api.FUNDAMENTAL_REPROJECTION_ERROR_THRESHOLD,
+                                                               r_inl, r_sum), ks, kw)
+        extra["ransac_score"] = {
+            "workload": "%d hypotheses x %d matched pairs: Lindstrom correction, triangulation, reprojection "
+                        "error, inlier count and in-order error sum per hypothesis" % (rh_, rn),
+            "ms": ms, "pair_evaluations_per_s": float(rh_) * rn / (ms * 1e-3),
+            "best_inliers": int(r_inl.max().item()),
+            "note": "includes the host-side record preparation and upload of each call",
+        }
     if not args.no_extra:
         # descriptor matching (BASELINE config 5).  With N > 1 ranks list1's queries are sharded
         # (list2 replicated, no data-path collective): strong scaling of the one 200k x 200k job.
@@ -439,6 +466,19 @@ def main():
                 "value": nsurv / dt_d, "unit": "features/s", "cores": 1,
                 "sample": "oracle_sift_descriptors, all %d features (%.2f s, single thread)" % (nsurv, dt_d),
                 "matches_gpu_on_sample": ok_d}
+            # hypothesis scoring: the oracle on the first 16 hypotheses (OpenMP over hypotheses)
+            nh_cpu = 16
+            t0 = time.perf_counter()
+            ci, cs_, _, _ = orc.ransac_score(recs[:nh_cpu], rk1, rk2, rp1, rp2, excl[:nh_cpu],
+                                             api.FUNDAMENTAL_REPROJECTION_ERROR_THRESHOLD)
+            dt_h = time.perf_counter() - t0
+            out["extra"]["cpu_ransac_score"] = {
+                "value": nh_cpu * rn / dt_h, "unit": "pair evaluations/s", "cores": min(nh_cpu, cores),
+                "sample": "oracle_ransac_score, first %d hypotheses x %d pairs, one thread per hypothesis "
+                          "(%.2f s)" % (nh_cpu, rn, dt_h),
+                "matches_gpu_on_sample": bool(np.array_equal(ci, r_inl[:nh_cpu].cpu().numpy())
+                                              and np.array_equal(cs_.view(np.uint32),
+                                                                 r_sum[:nh_cpu].cpu().numpy().view(np.uint32)))}
             # rectification: oracle_rectify on one image of the batch
             t0 = time.perf_counter()
             cr = orc.rectify(src_np[0], np.zeros((rh, rw), np.uint8), Hinv[0].reshape(3, 3))

@@ -6,6 +6,9 @@ Three data-parallel stages behind the reference's own function names:
     RectifyImage       stereo/Stereography.cpp:596-631
     ComputeDepthImage  stereo/Stereography.cpp:649-691
 
+plus the stages either side of them (FAST-12, scoring + suppression, descriptors, RANSAC
+hypothesis scoring).
+
 All compute happens in libstereo_hip.so (hand-written HIP for gfx950, C ABI in
 include/stereo_hip.h).  There is no CPU fallback: importing the compute entry
 points without the built library raises.
@@ -28,10 +31,11 @@ from .api import (
     NN_RATIO,
     MAX_DIST_BETWEEN_MATCHES,
 )
+from .ransac import FindFundamentalMatrixWithRANSAC
 
 __all__ = [
     "StereoHipError", "load_library", "library_path", "Context", "Feature",
-    "MatchDescriptors", "FindFASTFeatures", "ScoreAndClusterFeatures", "ClusterFeatures", "CreateSIFTDescriptors", "RectifyImage", "ComputeDepthImage",
+    "MatchDescriptors", "FindFASTFeatures", "ScoreAndClusterFeatures", "ClusterFeatures", "CreateSIFTDescriptors", "FindFundamentalMatrixWithRANSAC", "RectifyImage", "ComputeDepthImage",
     "MATCH_FAILED", "MATCH_SCORE", "MATCH_RATIO", "MATCH_ACCEPTED",
     "NN_RATIO", "MAX_DIST_BETWEEN_MATCHES",
 ]

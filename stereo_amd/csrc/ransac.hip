@@ -163,30 +163,96 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_error_kernel(
     errors[o] = sqrtf(dot3(w0, w1, w2, w0, w1, w2));
 }
 
-// One wave per hypothesis: localInliers and the running avgError of :232-236, the sum taken in
-// pair order.  An error that is not an inlier contributes +0, which leaves the (non-negative)
-// running sum unchanged, so the chain needs no branches; chunks without inliers are skipped.
+// One wave per hypothesis: localInliers and the running avgError of :232-236.  fp32 addition
+// does not reassociate, so the sum is a serial chain in pair order -- but only the inliers are
+// on it.  Per tile of RD_TILE errors the wave (a) compacts the inliers, in order, into LDS with
+// ballot / mbcnt prefix counts, all lanes working, then (b) runs the chain over the compacted
+// values, every lane redundantly, sixteen values per step with the next step's LDS reads in flight.  The
+// next tile's global loads are issued before (b), so the chain never waits on HBM.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// (`sum` is tied into both asm blocks so that the adds between them stay between them)
+__device__ __forceinline__ void lds_issue4(unsigned addr, f32x4 &r0, f32x4 &r1, f32x4 &r2, f32x4 &r3, float &sum)
+{
+    asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\t"
+                 "ds_read_b128 %2, %5 offset:32\n\tds_read_b128 %3, %5 offset:48"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "+v"(sum)
+                 : "v"(addr)
+                 : "memory");
+}
+// the reads above are complete after this
+__device__ __forceinline__ void lds_wait(f32x4 &r0, f32x4 &r1, f32x4 &r2, f32x4 &r3, float &sum)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(sum));
+}
+__device__ __forceinline__ void chain16(float &sum, const f32x4 &v0, const f32x4 &v1, const f32x4 &v2,
+                                        const f32x4 &v3)
+{
+    sum = sum + v0.x; sum = sum + v0.y; sum = sum + v0.z; sum = sum + v0.w;
+    sum = sum + v1.x; sum = sum + v1.y; sum = sum + v1.z; sum = sum + v1.w;
+    sum = sum + v2.x; sum = sum + v2.y; sum = sum + v2.z; sum = sum + v2.w;
+    sum = sum + v3.x; sum = sum + v3.y; sum = sum + v3.z; sum = sum + v3.w;
+}
+
+constexpr int RD_K = 8;               // values per lane per tile
+constexpr int RD_TILE = 64 * RD_K;
+
 __global__ __launch_bounds__(64) void ransac_reduce_kernel(const float *__restrict__ errors, int n, float threshold,
                                                            int32_t *__restrict__ inliers,
                                                            float *__restrict__ err_sum)
 {
+    __shared__ __align__(16) float list[RD_TILE + 32];
     const int h = blockIdx.x, lane = threadIdx.x;
     const float *e = errors + (size_t)h * n;
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) float *)list;
     float sum = 0.0f;
     int count = 0;
-    float next = lane < n ? e[lane] : -1.0f;
-    for (int base = 0; base < n; base += 64) {
-        const float cur = next;
-        const int j = base + 64 + lane;
-        next = j < n ? e[j] : -1.0f;
-        const bool in = cur >= 0.0f && cur < threshold;
-        const unsigned long long mask = __ballot(in);
-        if (mask == 0) continue;
-        count += __popcll(mask);
-        const float v = in ? cur : 0.0f;
+    float next[RD_K];
 #pragma unroll
-        for (int l = 0; l < 64; ++l)
-            sum = sum + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+    for (int k = 0; k < RD_K; ++k) {
+        const int j = k * 64 + lane;
+        next[k] = j < n ? e[j] : -1.0f;
+    }
+    for (int base = 0; base < n; base += RD_TILE) {
+        float cur[RD_K];
+#pragma unroll
+        for (int k = 0; k < RD_K; ++k) cur[k] = next[k];
+#pragma unroll
+        for (int k = 0; k < RD_K; ++k) {
+            const int j = base + RD_TILE + k * 64 + lane;
+            next[k] = j < n ? e[j] : -1.0f;
+        }
+        // (a) in-order compaction of this tile's inliers
+        int m = 0;
+#pragma unroll
+        for (int k = 0; k < RD_K; ++k) {
+            const bool in = cur[k] >= 0.0f && cur[k] < threshold;
+            const unsigned long long mask = __ballot(in);
+            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            if (in) list[m + before] = cur[k];
+            m += __popcll(mask);
+        }
+        if (m == 0) continue;
+        if (lane < 32) list[m + lane] = 0.0f;  // whole groups are read; a group past the end is all +0,
+        __syncthreads();                       // which leaves the (non-negative) sum as it is
+        // (b) the chain, 16 values per group.  The next group's four LDS reads are issued BEFORE
+        // the current group's adds and waited for after them: written as asm because the compiler
+        // otherwise sinks the reads to their uses and every group pays the LDS round trip.
+        const int groups = (m + 15) >> 4;
+        f32x4 a0, a1, a2, a3, b0, b1, b2, b3;
+        lds_issue4(lbase, a0, a1, a2, a3, sum);
+        lds_wait(a0, a1, a2, a3, sum);
+        for (int g = 0; g < groups; g += 2) {
+            lds_issue4(lbase + 64u * (unsigned)min(g + 1, groups), b0, b1, b2, b3, sum);
+            chain16(sum, a0, a1, a2, a3);
+            lds_wait(b0, b1, b2, b3, sum);
+            lds_issue4(lbase + 64u * (unsigned)min(g + 2, groups), a0, a1, a2, a3, sum);
+            chain16(sum, b0, b1, b2, b3);
+            lds_wait(a0, a1, a2, a3, sum);
+        }
+        count += m;
+        __syncthreads();
     }
     if (lane == 0) {
         inliers[h] = count;
