@@ -284,8 +284,9 @@ int stx_gaussian_kernel(int size, float sigma, float *out);
  * in pair order; errors (may be NULL; n_hyp x n): every pair's error, 1000 where Triangulate
  * fails, -1 for excluded pairs; depths (may be NULL; n_hyp x n x 2): Triangulate's depth0,
  * depth1 (NaN where it fails or the pair is excluded).  hyp, K1, K2, exclude are always host
- * arrays.  fp32 throughout, dot products summed left to right without contraction; parity with
- * Eigen's evaluation order is unpinned.  Host pointers. */
+ * arrays.  fp32 throughout, no contraction; three-term sums of fixed-size Eigen expressions as
+ * a0 + (a1 + a2) (Eigen's unrolled reduction); parity with Eigen itself is unpinned.
+ * Host pointers. */
 #define STX_HYP_FLOATS 36
 int stx_ransac_score(stx_ctx *ctx, const float *hyp, int n_hyp, const float K1[9], const float K2[9],
                      const float *p1, const float *p2, int n, const int32_t *exclude, float threshold,

@@ -703,8 +703,25 @@ void oracle_sift_descriptors(const uint8_t *gx, const uint8_t *gy, int w, int h,
 
 /* ---- RANSAC hypothesis scoring --------------------------------- */
 
-/* row r of a row-major 3x3 times a vector, summed left to right */
+/* Three-term sums of fixed-size Eigen expressions (Matrix3f * Vector3f, dot(), norm()) go
+ * through Eigen's unrolled reduction, which splits 3 terms as a0 + (a1 + a2) -- the same
+ * order oracle_rectify uses for H^-1 * x.  Row r of a row-major 3x3 times a vector: */
 static float row_dot3(const float *m, int r, const float v[3])
+{
+    float a0 = m[r * 3] * v[0], a1 = m[r * 3 + 1] * v[1], a2 = m[r * 3 + 2] * v[2];
+    return a0 + (a1 + a2);
+}
+
+/* column c of a row-major 3x3 times a vector (a row vector times the matrix) */
+static float col_dot3(const float *m, int c, const float v[3])
+{
+    float a0 = m[c] * v[0], a1 = m[3 + c] * v[1], a2 = m[6 + c] * v[2];
+    return a0 + (a1 + a2);
+}
+
+/* The products through the dynamic-size selector S (MatrixXf, :356-363) take Eigen's run-time
+ * paths instead; there the three terms are accumulated in index order. */
+static float row_dot3_seq(const float *m, int r, const float v[3])
 {
     float s = m[r * 3] * v[0];
     s = s + m[r * 3 + 1] * v[1];
@@ -712,8 +729,7 @@ static float row_dot3(const float *m, int r, const float v[3])
     return s;
 }
 
-/* column c of a row-major 3x3 times a vector (a row vector times the matrix) */
-static float col_dot3(const float *m, int c, const float v[3])
+static float col_dot3_seq(const float *m, int c, const float v[3])
 {
     float s = m[c] * v[0];
     s = s + m[3 + c] * v[1];
@@ -725,17 +741,15 @@ void oracle_lindstrom(float x[3], float xp[3], const float E[9])
 {
     /* Etilde = S E S^T is E's upper-left 2x2 (:360); S only selects rows */
     const float e00 = E[0], e01 = E[1], e10 = E[3], e11 = E[4];
-    float n0 = row_dot3(E, 0, xp), n1 = row_dot3(E, 1, xp);  /* n = S E x' (:362) */
-    float m0 = col_dot3(E, 0, x), m1 = col_dot3(E, 1, x);    /* n' = S E^T x (:363) */
+    float n0 = row_dot3_seq(E, 0, xp), n1 = row_dot3_seq(E, 1, xp);  /* n = S E x' (:362) */
+    float m0 = col_dot3_seq(E, 0, x), m1 = col_dot3_seq(E, 1, x);    /* n' = S E^T x (:363) */
     /* a = n^T Etilde n' (:366): the row vector n^T Etilde first */
     float r0 = n0 * e00 + n1 * e10, r1 = n0 * e01 + n1 * e11;
     float a = r0 * m0 + r1 * m1;
     float b = 0.5f * ((n0 * n0 + n1 * n1) + (m0 * m0 + m1 * m1)); /* :367 */
     /* c = x^T E x' (:368): the row vector x^T E first */
     float q[3] = {col_dot3(E, 0, x), col_dot3(E, 1, x), col_dot3(E, 2, x)};
-    float c = q[0] * xp[0];
-    c = c + q[1] * xp[1];
-    c = c + q[2] * xp[2];
+    float c = q[0] * xp[0] + (q[1] * xp[1] + q[2] * xp[2]);
     float d = sqrtf(b * b - a * c);
     float lambda = c / (b + d);
     float xd0 = lambda * n0, xd1 = lambda * n1;    /* x_delta (:371) */
@@ -760,10 +774,8 @@ void oracle_lindstrom(float x[3], float xp[3], const float E[9])
 
 static float dot3(const float a[3], const float b[3])
 {
-    float s = a[0] * b[0];
-    s = s + a[1] * b[1];
-    s = s + a[2] * b[2];
-    return s;
+    float p0 = a[0] * b[0], p1 = a[1] * b[1], p2 = a[2] * b[2];
+    return p0 + (p1 + p2);
 }
 
 int oracle_triangulate(float *depth0, float *depth1, float x[3], float xp[3], const float E[9],

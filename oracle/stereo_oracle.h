@@ -160,8 +160,10 @@ void oracle_sift_descriptors(const uint8_t *gx, const uint8_t *gy, int w, int h,
 
 /* ---- RANSAC hypothesis scoring ---------------------------------
  * PARITY UNPINNED against Eigen: the reference evaluates these 3x3 / 2x2 expressions through
- * Eigen templates whose summation order is not visible in its own source; here every dot
- * product is summed left to right in fp32, without contraction.  The singular value
+ * Eigen templates whose summation order is not visible in its own source; here three-term sums
+ * of fixed-size expressions follow Eigen's unrolled reduction, a0 + (a1 + a2) (as oracle_rectify
+ * does), the products through the dynamic-size selector S (:356-363) are accumulated in index
+ * order, all in fp32 without contraction.  The singular value
  * decompositions (DecomposeEssentialMatrix, Stereography.cpp:301-353) are NOT restated: their
  * outputs are inputs here, one record per hypothesis:
  *   hyp[0..8]   E, row-major, as the call at :225 leaves it (scaled by its first singular value)

@@ -3,6 +3,7 @@
 //   stereo/Features.cpp:1020-1079      (MatchDescriptors)
 //   stereo/Stereography.cpp:596-631    (RectifyImage)
 //   stereo/Stereography.cpp:649-691    (ComputeDepthImage)
+//   stereo/Stereography.cpp:184-281    (FindFundamentalMatrixWithRANSAC; its pair loop runs on the GPU)
 // The including translation unit must already see the reference's `Feature`
 // (stereo/Features.h:52-84), cv::Mat and Eigen::Matrix3f.  Signatures, ownership and
 // printed lines are the reference's.
@@ -167,6 +168,108 @@ inline bool CreateSIFTDescriptorsOnGradients(const cv::Mat &grad_x, const cv::Ma
         descriptors.push_back(features[i].desc);  // :933
     }
     return true;
+}
+
+// Stereography.h:29 (body Stereography.cpp:184-281).  The including translation unit must see the
+// reference's StereoPair, FindFundamentalMatrix (Stereography.h:28), DecomposeEssentialMatrix
+// (Stereography.h:35-39) and the FUNDAMENTAL_* / MIN_NUM_INLIERS macros (Stereography.h:11-13):
+// the draws, the eight-point solves and the Eigen decompositions stay the reference's own host
+// code.  Neither depends on the scores, so all iterations' hypotheses are made first, the pair
+// loop of every iteration (:226-238) runs in ONE stx_ransac_score call, and the selection rule
+// (:239-246, :275-280) is applied in iteration order afterwards.
+inline bool FindFundamentalMatrixWithRANSAC(const std::vector<std::pair<Feature, Feature> > &matches,
+                                            Eigen::Matrix3f &F, StereoPair &stereo)
+{
+    using namespace stereo_hip_dropin;
+    const int n = (int)matches.size();
+    if (n < 8) return false;  // the reference's draw loop takes rand() % 0 here
+    const int iterations = FUNDAMENTAL_RANSAC_ITERATIONS;
+    srand(F(0, 0));  // :193, kept: the seed is whatever the caller's F holds
+
+    std::vector<Eigen::Matrix3f> fundamentals;
+    std::vector<float> hyp;
+    std::vector<int32_t> exclude;
+    std::vector<int> left;
+    for (int it = 0; it < iterations; ++it) {
+        // :200-211 with positions in place of copies of the pair list
+        left.resize(n);
+        for (int i = 0; i < n; ++i) left[i] = i;
+        std::vector<std::pair<Feature, Feature> > chosenEight;
+        int32_t chosen[8];
+        while (chosenEight.size() < 8) {
+            const int randNum = rand() % left.size();
+            chosen[chosenEight.size()] = left[randNum];
+            chosenEight.push_back(matches[left[randNum]]);
+            left.erase(left.begin() + randNum);
+        }
+        Eigen::Matrix3f fundamental;
+        if (!FindFundamentalMatrix(chosenEight, fundamental)) continue;  // :214
+        Eigen::Matrix3f E = stereo.img2.K.transpose() * fundamental * stereo.img1.K;  // :220
+        Eigen::Matrix3f R, R2;
+        R.setZero();
+        R2.setZero();
+        Eigen::Vector3f t(0, 0, 0);
+        DecomposeEssentialMatrix(E, R2, R, t);  // :225; scales E in place (:318)
+        // every ReprojectionError call decomposes its by-value copy of E again inside Triangulate
+        // (:163, :398): the same matrices for all pairs, so once here
+        Eigen::Matrix3f Ecopy = E, Rin, Rother;
+        Rin.setZero();
+        Rother.setZero();
+        Eigen::Vector3f tin(0, 0, 0);
+        const bool inner = DecomposeEssentialMatrix(Ecopy, Rother, Rin, tin);
+        float rec[STX_HYP_FLOATS] = {0};
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) {
+                rec[r * 3 + c] = E(r, c);
+                rec[9 + r * 3 + c] = R(r, c);
+                rec[21 + r * 3 + c] = Rin(r, c);
+            }
+            rec[18 + r] = t(r);
+            rec[30 + r] = tin(r);
+        }
+        rec[33] = inner ? 1.f : 0.f;
+        hyp.insert(hyp.end(), rec, rec + STX_HYP_FLOATS);
+        exclude.insert(exclude.end(), chosen, chosen + 8);
+        fundamentals.push_back(fundamental);
+    }
+
+    const int n_hyp = (int)fundamentals.size();
+    std::vector<float> p1(2 * (size_t)n), p2(2 * (size_t)n), err_sum((size_t)n_hyp);
+    std::vector<int32_t> inliers((size_t)n_hyp);
+    float k1[9], k2[9];
+    for (int i = 0; i < n; ++i) {
+        p1[2 * (size_t)i] = matches[i].first.p.x;
+        p1[2 * (size_t)i + 1] = matches[i].first.p.y;
+        p2[2 * (size_t)i] = matches[i].second.p.x;
+        p2[2 * (size_t)i + 1] = matches[i].second.p.y;
+    }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            k1[r * 3 + c] = stereo.img1.K(r, c);
+            k2[r * 3 + c] = stereo.img2.K(r, c);
+        }
+    check(stx_ransac_score(context(), hyp.data(), n_hyp, k1, k2, p1.data(), p2.data(), n, exclude.data(),
+                           (float)FUNDAMENTAL_REPROJECTION_ERROR_THRESHOLD, inliers.data(), err_sum.data(),
+                           nullptr, nullptr),
+          "stx_ransac_score");
+
+    // :239-246 in iteration order; minError is an int in the reference (:191)
+    Eigen::Matrix3f currentBestFundamentalMatrix;
+    int minError = FUNDAMENTAL_REPROJECTION_ERROR_THRESHOLD * MIN_NUM_INLIERS;
+    for (int h = 0; h < n_hyp; ++h) {
+        const int localInliers = inliers[h];
+        float avgError = err_sum[h];
+        if (localInliers > 0) avgError /= localInliers;
+        if (localInliers > MIN_NUM_INLIERS && avgError < minError) {
+            minError = avgError;
+            currentBestFundamentalMatrix = fundamentals[h];
+        }
+    }
+    if (minError < FUNDAMENTAL_REPROJECTION_ERROR_THRESHOLD * MIN_NUM_INLIERS) {  // :275-280
+        F = currentBestFundamentalMatrix;
+        return true;
+    }
+    return false;
 }
 
 // Stereography.h:48-51.  H is the forward homography; `rectified` is in/out.

@@ -10,8 +10,8 @@
 // the same matrix for every pair of a hypothesis: it is a per-hypothesis input as well.
 //
 // Arithmetic: fp32, every multiply, add, divide and sqrt its own correctly rounded operation
-// (-ffp-contract=off), dot products summed left to right -- the order an unoptimised build of
-// the reference's Eigen expressions evaluates them in.  The error sum of a hypothesis is taken
+// (-ffp-contract=off); three-term sums of fixed-size Eigen expressions as a0 + (a1 + a2), Eigen's
+// unrolled reduction (the order the rectification kernel already follows).  The error sum of a hypothesis is taken
 // in pair order by a serial chain (fp32 addition does not reassociate), one wave per hypothesis.
 //
 // Bound: compute (about 30 IEEE divisions and square roots per evaluation); 16 B of pair data
@@ -31,7 +31,29 @@ struct Cams {
     float k1inv[9], k2inv[9], k2[9];
 };
 
+// Three-term sums of fixed-size Eigen expressions (Matrix3f * Vector3f, dot(), norm()) follow
+// Eigen's unrolled reduction, a0 + (a1 + a2), as in the rectification kernel.
 __device__ __forceinline__ float row_dot3(const float *m, int r, float v0, float v1, float v2)
+{
+    const float a0 = m[r * 3] * v0, a1 = m[r * 3 + 1] * v1, a2 = m[r * 3 + 2] * v2;
+    return a0 + (a1 + a2);
+}
+
+__device__ __forceinline__ float col_dot3(const float *m, int c, float v0, float v1, float v2)
+{
+    const float a0 = m[c] * v0, a1 = m[3 + c] * v1, a2 = m[6 + c] * v2;
+    return a0 + (a1 + a2);
+}
+
+__device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, float b1, float b2)
+{
+    const float p0 = a0 * b0, p1 = a1 * b1, p2 = a2 * b2;
+    return p0 + (p1 + p2);
+}
+
+// The products through the dynamic-size selector S (MatrixXf, :356-363) take Eigen's run-time
+// paths: three terms accumulated in index order.
+__device__ __forceinline__ float row_dot3_seq(const float *m, int r, float v0, float v1, float v2)
 {
     float s = m[r * 3] * v0;
     s = s + m[r * 3 + 1] * v1;
@@ -39,19 +61,11 @@ __device__ __forceinline__ float row_dot3(const float *m, int r, float v0, float
     return s;
 }
 
-__device__ __forceinline__ float col_dot3(const float *m, int c, float v0, float v1, float v2)
+__device__ __forceinline__ float col_dot3_seq(const float *m, int c, float v0, float v1, float v2)
 {
     float s = m[c] * v0;
     s = s + m[3 + c] * v1;
     s = s + m[6 + c] * v2;
-    return s;
-}
-
-__device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, float b1, float b2)
-{
-    float s = a0 * b0;
-    s = s + a1 * b1;
-    s = s + a2 * b2;
     return s;
 }
 
@@ -87,9 +101,9 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_error_kernel(
     // ---- LindstromOptimisation, :354-381 ------------------------------------
     {
         const float e00 = E[0], e01 = E[1], e10 = E[3], e11 = E[4];
-        float n0 = row_dot3(E, 0, y0, y1, y2), n1 = row_dot3(E, 1, y0, y1, y2);
+        float n0 = row_dot3_seq(E, 0, y0, y1, y2), n1 = row_dot3_seq(E, 1, y0, y1, y2);
+        float m0 = col_dot3_seq(E, 0, x0, x1, x2), m1 = col_dot3_seq(E, 1, x0, x1, x2);
         const float q0 = col_dot3(E, 0, x0, x1, x2), q1 = col_dot3(E, 1, x0, x1, x2), q2 = col_dot3(E, 2, x0, x1, x2);
-        float m0 = q0, m1 = q1;
         const float r0 = n0 * e00 + n1 * e10, r1 = n0 * e01 + n1 * e11;
         const float a = r0 * m0 + r1 * m1;
         const float b = 0.5f * ((n0 * n0 + n1 * n1) + (m0 * m0 + m1 * m1));
@@ -263,8 +277,8 @@ __global__ __launch_bounds__(64) void ransac_reduce_kernel(const float *__restri
 float host_row_dot3(const float *m, int r, const float v[3])
 {
     volatile float a = m[r * 3] * v[0], b = m[r * 3 + 1] * v[1], c = m[r * 3 + 2] * v[2];
-    volatile float s = a + b;
-    return s + c;
+    volatile float s = b + c;
+    return a + s;
 }
 
 }  // namespace

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <sstream>
+#include <vector>
 
 // struct Feature as the reference declares it (stereo/Features.h:46-84), minus stream operators
 #define DESC_LENGTH 128
@@ -16,8 +17,54 @@ struct Feature {
     float distFromBestMatch; float depth;
 };
 
+// What the reference's Stereography.h gives the adapter's FindFundamentalMatrixWithRANSAC
+// (Stereography.h:11-39).  The two solver functions are TEST STAND-INS defined below (the real
+// ones are Eigen BDCSVD code): they only have to be deterministic functions of their inputs.
+#define FUNDAMENTAL_REPROJECTION_ERROR_THRESHOLD 70
+#define MIN_NUM_INLIERS 20
+#define FUNDAMENTAL_RANSAC_ITERATIONS 200
+struct ImageDescriptor { Eigen::Matrix3f K; };
+struct StereoPair { ImageDescriptor img1, img2; Eigen::Matrix3f F, E; };
+bool FindFundamentalMatrix(const std::vector<std::pair<Feature, Feature> > &matches, Eigen::Matrix3f &F);
+bool DecomposeEssentialMatrix(Eigen::Matrix3f &E, Eigen::Matrix3f &R1, Eigen::Matrix3f &R2, Eigen::Vector3f &t);
+
 #include "stereo_dropin.hpp"
 #include "stereo_oracle.h"
+
+// ---- two-view scene for the RANSAC test: X2 = R X1 + t ---------------------------
+static const float SC_R[9] = {0.99939083f, 0.f, 0.0348995f, 0.f, 1.f, 0.f, -0.0348995f, 0.f, 0.99939083f};
+static const float SC_T[3] = {-0.99503719f, 0.0497519f, 0.0870658f};  // unit length
+static Eigen::Matrix3f sc_true_f;  // p2^T F p1 = 0, F(2,2) = 1
+
+// stand-in for the eight-point solve: the true F, nudged by the first chosen pair so that
+// hypotheses differ; every 7th draw "fails" (:214 takes that branch)
+bool FindFundamentalMatrix(const std::vector<std::pair<Feature, Feature> > &matches, Eigen::Matrix3f &F)
+{
+    if (matches.size() < 8) return false;
+    const int key = (int)matches[0].first.p.x;
+    if (key % 7 == 0) return false;
+    F = sc_true_f;
+    const float bend = (float)(key % 13) * 2e-9f;
+    F(0, 1) += bend;
+    F(1, 0) -= bend;
+    return true;
+}
+
+// stand-in for the SVD: scales E to unit singular values (:317-318, in place) and returns the
+// scene's rotation and baseline; fails on every third call for a matrix whose E(0,0) bit pattern is odd
+bool DecomposeEssentialMatrix(Eigen::Matrix3f &E, Eigen::Matrix3f &R1, Eigen::Matrix3f &R2, Eigen::Vector3f &t)
+{
+    float fro = 0;
+    for (float v : E.m) fro += v * v;
+    const float s = std::sqrt(fro / 2.f);
+    for (float &v : E.m) v /= s;
+    for (int i = 0; i < 9; ++i) R2.m[i] = SC_R[i];
+    R1 = R2.transpose();
+    for (int i = 0; i < 3; ++i) t(i) = SC_T[i];
+    uint32_t bits;
+    std::memcpy(&bits, &E.m[1], 4);
+    return (bits & 7u) != 0;
+}
 
 static uint64_t rng_state = 12345;
 static uint32_t rnd() { rng_state = rng_state * 6364136223846793005ULL + 1442695040888963407ULL; return (uint32_t)(rng_state >> 33); }
@@ -163,6 +210,82 @@ int main()
             if (std::memcmp(good[i].desc.vec, &odesc[128 * (size_t)i], 512) != 0) ++fails;
         }
         std::printf("descriptor fails so far: %d\n", fails);
+    }
+    {   // FindFundamentalMatrixWithRANSAC: the batched call against the reference's sequential loop
+        const int n = 600;
+        StereoPair stereo;
+        const float k1[9] = {2592.f, 0.f, 1440.f, 0.f, 2592.f, 994.f, 0.f, 0.f, 1.f};
+        const float k2[9] = {2617.92f, 0.f, 1447.f, 0.f, 2617.92f, 990.f, 0.f, 0.f, 1.f};
+        for (int i = 0; i < 9; ++i) { stereo.img1.K.m[i] = k1[i]; stereo.img2.K.m[i] = k2[i]; }
+        // F = K2^-T [t]x R K1^-1, scaled to F(2,2) = 1 (double precision, then rounded)
+        {
+            const double tx[9] = {0, -SC_T[2], SC_T[1], SC_T[2], 0, -SC_T[0], -SC_T[1], SC_T[0], 0};
+            double e[9], k1i[9] = {1 / 2592., 0, -1440. / 2592., 0, 1 / 2592., -994. / 2592., 0, 0, 1},
+                   k2i[9] = {1 / 2617.92, 0, -1447. / 2617.92, 0, 1 / 2617.92, -990. / 2617.92, 0, 0, 1}, a[9], f[9];
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { e[r * 3 + c] = 0; for (int k = 0; k < 3; ++k) e[r * 3 + c] += tx[r * 3 + k] * SC_R[k * 3 + c]; }
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { a[r * 3 + c] = 0; for (int k = 0; k < 3; ++k) a[r * 3 + c] += k2i[k * 3 + r] * e[k * 3 + c]; }
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { f[r * 3 + c] = 0; for (int k = 0; k < 3; ++k) f[r * 3 + c] += a[r * 3 + k] * k1i[k * 3 + c]; }
+            for (int i = 0; i < 9; ++i) sc_true_f.m[i] = (float)(f[i] / f[8]);
+        }
+        std::vector<std::pair<Feature, Feature> > matches(n);
+        for (int i = 0; i < n; ++i) {
+            const double X[3] = {-2.5 + 5.0 * (rnd() % 10000) / 10000., -1.7 + 3.4 * (rnd() % 10000) / 10000., 4 + 8.0 * (rnd() % 10000) / 10000.};
+            double Y[3];
+            for (int r = 0; r < 3; ++r) Y[r] = SC_R[r * 3] * X[0] + SC_R[r * 3 + 1] * X[1] + SC_R[r * 3 + 2] * X[2] + 0.4 * SC_T[r];
+            matches[i].first.p.x = (float)(k1[0] * X[0] / X[2] + k1[2]);
+            matches[i].first.p.y = (float)(k1[4] * X[1] / X[2] + k1[5]);
+            matches[i].second.p.x = (float)(k2[0] * Y[0] / Y[2] + k2[2]);
+            matches[i].second.p.y = (float)(k2[4] * Y[1] / Y[2] + k2[5]);
+            if (rnd() % 4 == 0) { matches[i].second.p.x = (float)(rnd() % 2880); matches[i].second.p.y = (float)(rnd() % 1988); }
+        }
+        Eigen::Matrix3f F;
+        F(0, 0) = 17.f;  // the seed, :193
+        const bool got = FindFundamentalMatrixWithRANSAC(matches, F, stereo);
+
+        // the reference's loop, sequentially, with the oracle's ReprojectionError
+        Eigen::Matrix3f best;
+        int minError = FUNDAMENTAL_REPROJECTION_ERROR_THRESHOLD * MIN_NUM_INLIERS, solved = 0, failed_inner = 0;
+        srand(17);
+        float k1inv[9], k2inv[9];
+        oracle_invert3x3(k1, k1inv);
+        oracle_invert3x3(k2, k2inv);
+        for (int it = 0; it < FUNDAMENTAL_RANSAC_ITERATIONS; ++it) {
+            std::vector<std::pair<Feature, Feature> > pairs(matches), chosenEight;
+            while (chosenEight.size() < 8) {
+                const int randNum = rand() % pairs.size();
+                chosenEight.push_back(pairs[randNum]);
+                pairs.erase(pairs.begin() + randNum);
+            }
+            Eigen::Matrix3f fundamental;
+            if (!FindFundamentalMatrix(chosenEight, fundamental)) continue;
+            ++solved;
+            Eigen::Matrix3f E = stereo.img2.K.transpose() * fundamental * stereo.img1.K, R, R2, Rin, Rother;
+            Eigen::Vector3f t, tin;
+            DecomposeEssentialMatrix(E, R2, R, t);
+            Eigen::Matrix3f Ecopy = E;
+            const bool inner = DecomposeEssentialMatrix(Ecopy, Rother, Rin, tin);
+            failed_inner += !inner;
+            float rec[ORACLE_HYP_FLOATS] = {0};
+            for (int i = 0; i < 9; ++i) { rec[i] = E.m[i]; rec[9 + i] = R.m[i]; rec[21 + i] = Rin.m[i]; }
+            for (int i = 0; i < 3; ++i) { rec[18 + i] = t(i); rec[30 + i] = tin(i); }
+            rec[33] = inner ? 1.f : 0.f;
+            int localInliers = 0;
+            float avgError = 0;
+            for (auto &m : pairs) {
+                const float q1[2] = {m.first.p.x, m.first.p.y}, q2[2] = {m.second.p.x, m.second.p.y};
+                const float e = oracle_reprojection_error(rec, k1inv, k2inv, k2, q1, q2, nullptr, nullptr);
+                if (e < FUNDAMENTAL_REPROJECTION_ERROR_THRESHOLD) { localInliers++; avgError += e; }
+            }
+            if (localInliers > 0) avgError /= localInliers;
+            if (localInliers > MIN_NUM_INLIERS && avgError < minError) { minError = avgError; best = fundamental; }
+        }
+        const bool want = minError < FUNDAMENTAL_REPROJECTION_ERROR_THRESHOLD * MIN_NUM_INLIERS;
+        if (got != want || !want) ++fails;
+        if (std::memcmp(F.m, best.m, sizeof best.m) != 0) ++fails;
+        if (solved < 100 || solved == FUNDAMENTAL_RANSAC_ITERATIONS || failed_inner == 0) ++fails;  // every branch taken
+        std::vector<std::pair<Feature, Feature> > few(matches.begin(), matches.begin() + 7);
+        if (FindFundamentalMatrixWithRANSAC(few, F, stereo)) ++fails;
+        std::printf("RANSAC fails so far: %d (solved %d, inner failures %d, minError %d)\n", fails, solved, failed_inner, minError);
     }
     std::printf(fails ? "DROPIN FAIL\n" : "DROPIN OK\n");
     return fails ? 1 : 0;
