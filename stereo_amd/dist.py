@@ -124,3 +124,14 @@ def match_sharded(compute_queries, n1, group=None, gather=True):
     counts = [shard_range(n1, r, world)[1] - shard_range(n1, r, world)[0] for r in range(world)]
     res = [gather_rows(p, counts, 0, group) for p in parts]
     return tuple(res) if rank == 0 else None
+
+
+def ransac_sharded(compute_hypotheses, n_hyp, group=None, gather=True):
+    """Hypothesis-sharded RANSAC scoring: rank r scores hypotheses
+    shard_range(n_hyp, r, world) over the whole (replicated) pair list -- hypotheses are
+    independent, so there is no exchange.
+
+    compute_hypotheses(lo, hi) -> (inliers, err_sum) tensors of length hi-lo.  gather=True
+    concatenates them on rank 0 in iteration order (the order the selection rule of
+    Stereography.cpp:239-246 walks them in), None elsewhere."""
+    return match_sharded(compute_hypotheses, n_hyp, group, gather)

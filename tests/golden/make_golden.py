@@ -63,8 +63,29 @@ def features():
                         cluster_score=cscore, cluster_index=cidx)
 
 
+def ransac():
+    # N2: hypothesis scoring on one small two-view scene (8 hypotheses x 96 pairs)
+    from stereo_amd import ransac as rs
+    k1, k2, p1, p2, fm = synth.two_view_matches(31, 96)
+    rng = rs.msvc_rand(2)
+    recs, excl = [rs.hypothesis_record(fm, k1, k2)], [rs.draw_eight(96, rng)]
+    while len(recs) < 8:
+        ch = rs.draw_eight(96, rng)
+        ok, f8 = rs.find_fundamental_matrix(p1[ch], p2[ch])
+        rec = rs.hypothesis_record(f8, k1, k2) if ok else None
+        if rec is not None:
+            recs.append(rec)
+            excl.append(ch)
+    recs, excl = np.stack(recs), np.array(excl, np.int32)
+    recs[5, 33] = 0   # one hypothesis whose inner decomposition failed
+    inl, tot, err, dep = o.ransac_score(recs, k1, k2, p1, p2, excl, 70.0)
+    np.savez_compressed(os.path.join(HERE, "n2_ransac_8x96.npz"), hyp=recs, exclude=excl, K1=k1, K2=k2, p1=p1,
+                        p2=p2, inliers=inl, err_sum=tot, errors=err, depths=dep)
+
+
 def main():
     features()
+    ransac()
     # D, reference mode
     l, r = synth.rectified_pair(1234, 48, 64, 16)
     np.savez_compressed(os.path.join(HERE, "d_ref_64x48.npz"), img0=l, img1=r,

@@ -103,6 +103,22 @@ def _worker_rm(rank, world, port, q):
                 ok = ok and g.numpy().tobytes() == wnt.tobytes()
         else:
             ok = ok and res is None
+
+        # hypothesis-sharded RANSAC scoring (N2): golden records, 8 hypotheses over 2 ranks
+        from stereo_amd.dist import ransac_sharded
+        g = np.load(os.path.join(ROOT, "tests", "golden", "n2_ransac_8x96.npz"))
+
+        def hyps(lo, hi):
+            inl, tot, _, _ = o.ransac_score(g["hyp"][lo:hi], g["K1"], g["K2"], g["p1"], g["p2"],
+                                            g["exclude"][lo:hi], 70.0)
+            return torch.from_numpy(inl), torch.from_numpy(tot)
+
+        res = ransac_sharded(hyps, 8)
+        if rank == 0:
+            ok = ok and res[0].numpy().tolist() == g["inliers"].tolist()
+            ok = ok and res[1].numpy().tobytes() == g["err_sum"].tobytes()
+        else:
+            ok = ok and res is None
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

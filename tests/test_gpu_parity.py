@@ -1041,3 +1041,11 @@ def test_find_fundamental_matrix_with_ransac(ctx, oracle):
     assert np.array_equal(f, f2)
     ok3, f3 = ransac.FindFundamentalMatrixWithRANSAC(p1, p2, k1, k2, seed=5, ctx=ctx)
     assert ok3 and not np.array_equal(f, f3)   # another seed draws other pairs
+
+
+def test_ransac_golden_vectors_gpu(ctx):
+    g = np.load(os.path.join(GOLD, "n2_ransac_8x96.npz"))
+    inl, tot, err, dep = ctx.ransac_score(g["hyp"], g["K1"], g["K2"], g["p1"], g["p2"], exclude=g["exclude"],
+                                          want_errors=True, want_depths=True)
+    assert inl.tolist() == g["inliers"].tolist() and _same_f32(tot, g["err_sum"])
+    assert _same_f32(err, g["errors"]) and _same_f32(dep, g["depths"])

@@ -706,3 +706,13 @@ def test_find_fundamental_matrix_satisfies_the_epipolar_constraint():
     scale = np.abs(f8).max() * 2880 * 2880
     assert np.abs(res).max() < 1e-3 * scale
     assert ransac.find_fundamental_matrix(p1[:7], p2[:7]) == (False, None)   # :79-82
+
+
+def test_ransac_golden_vectors(oracle):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "n2_ransac_8x96.npz"))
+    inl, tot, err, dep = oracle.ransac_score(g["hyp"], g["K1"], g["K2"], g["p1"], g["p2"], g["exclude"], 70.0)
+    assert inl.tolist() == g["inliers"].tolist() and tot.tobytes() == g["err_sum"].tobytes()
+    assert np.array_equal(err, g["errors"], equal_nan=True) and np.array_equal(dep, g["depths"], equal_nan=True)
+    assert (g["errors"][5][g["errors"][5] >= 0] == 1000).all()      # the failed inner decomposition (:172)
+    assert (g["errors"] == -1).sum() == 8 * 8 and g["inliers"].max() > 20

@@ -31,6 +31,6 @@ torch.cuda.synchronize()
 for rep in range(3):
     t0 = time.perf_counter()
     for _ in range(10):
-        ctx.ransac_score_dev(recs, k1, k2, d1, d2, excl, 70.0, inl, tot)
+        ctx.ransac_score_dev(recs, k1, k2, d1, d2, excl, float(os.environ.get("RS_THRESHOLD", "70")), inl, tot)
     ctx.synchronize()
     print("ms per call: %.3f" % ((time.perf_counter() - t0) * 100), "inliers", np.sort(inl.cpu().numpy())[-3:])
