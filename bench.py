@@ -466,8 +466,8 @@ def main():
                 "value": nsurv / dt_d, "unit": "features/s", "cores": 1,
                 "sample": "oracle_sift_descriptors, all %d features (%.2f s, single thread)" % (nsurv, dt_d),
                 "matches_gpu_on_sample": ok_d}
-            # hypothesis scoring: the oracle on the first 16 hypotheses (OpenMP over hypotheses)
-            nh_cpu = 16
+            # hypothesis scoring: the oracle on the first 64 hypotheses (OpenMP over hypotheses)
+            nh_cpu = min(rh_, 64)
             t0 = time.perf_counter()
             ci, cs_, _, _ = orc.ransac_score(recs[:nh_cpu], rk1, rk2, rp1, rp2, excl[:nh_cpu],
                                              api.FUNDAMENTAL_REPROJECTION_ERROR_THRESHOLD)

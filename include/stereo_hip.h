@@ -286,7 +286,8 @@ int stx_gaussian_kernel(int size, float sigma, float *out);
  * depth1 (NaN where it fails or the pair is excluded).  hyp, K1, K2, exclude are always host
  * arrays.  fp32 throughout, no contraction; three-term sums of fixed-size Eigen expressions as
  * a0 + (a1 + a2) (Eigen's unrolled reduction); parity with Eigen itself is unpinned.
- * Host pointers. */
+ * n_hyp <= 65535; when errors is NULL the library keeps the n_hyp x n errors in a grow-only
+ * workspace of its own (4 bytes each).  Host pointers. */
 #define STX_HYP_FLOATS 36
 int stx_ransac_score(stx_ctx *ctx, const float *hyp, int n_hyp, const float K1[9], const float K2[9],
                      const float *p1, const float *p2, int n, const int32_t *exclude, float threshold,
