@@ -200,7 +200,7 @@ __global__ __launch_bounds__(EXT_THREADS) void disp_ext_bruteforce_kernel(
 
 
 // ---------------------------------------------------------------------------
-// D1-ext, sliding-sum kernel (SAD, window radius 0..4, any max_disp).
+// D1-ext, sliding-sum kernel (SAD, window radius 0..6; SSD radius 1..5; any max_disp).
 //
 // Work decomposition
 //   workgroup = one tile of 256 image columns x one band of `bh` output rows;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(EXT_THREADS) void disp_ext_bruteforce_kernel(
 // from registers filled by 128-bit LDS reads (one lane = 4 columns = one b128).
 // The horizontal window sum slides across the lane's 4 columns and takes the
 // columns it lacks from the neighbouring lanes with wave_shr:1 / wave_shl:1 DPP
-// adds (window radius <= 4 => one lane to each side).  The key
+// adds (window radius <= 4 => one lane to each side; radius 5, 6 => two, with chained hops).  The key
 //     (cost << BAND_SH) + (4095 - d) + mask(img1[y][x-d] == 0 or x-d < 0)
 // is reduced with v_min3_u32 over the wave's 16 disparities, then across the
 // workgroup's waves with one LDS atomic min per pixel: smallest cost wins, equal
@@ -369,8 +369,10 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     // of disparities.  key = cost << 16 | (65535 - d).  Disparities past D start from PK_PAST per
     // column, which lifts their costs above every valid one (PK_PAST > 255 * WIN) without
     // leaving the half-word (WIN * (PK_PAST + 255 * WIN) < 65536).
-    constexpr bool PK = !SSD && R > 0;
-    constexpr unsigned PK_PAST = 3584u;
+    constexpr bool PK = !SSD && R > 0 && R <= 5;
+    constexpr unsigned PK_PAST = WIN <= 9 ? 3584u : 3000u;
+    static_assert(!PK || (PK_PAST > 255u * WIN && WIN * (PK_PAST + 255u * WIN) < 65536u), "half-word costs");
+    static_assert(!SSD || (unsigned long long)WIN * WIN * 65025ull * 256ull < (1ull << 31), "SSD key width");
     constexpr unsigned SH = PK ? 16u : SSD ? 8u : BAND_SH;  // key = cost << SH | code
     constexpr unsigned PSH = PK ? 0u : SSD ? 4u : BAND_SH;  // pixel pre-shift in the ring
     constexpr unsigned LOW = (1u << SH) - 1;
@@ -545,6 +547,29 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
                 if (R == 0) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) cost[c] = W1[dd][c];
+                } else if constexpr (R > 4) {
+                    // R = 5, 6: the window spans two lanes to each side.  cost[0] = this lane's
+                    // and the left lane's four columns, columns 8-R..3 of the lane two to the
+                    // left and columns 0..R-4 of the right lane
+                    const unsigned all4 = (V[dd][0] + V[dd][1]) + (V[dd][2] + V[dd][3]);
+                    unsigned suffix2 = V[dd][3];
+#pragma unroll
+                    for (int c = 2; c >= 8 - R; --c) suffix2 += V[dd][c];
+                    unsigned prefix = V[dd][0];
+#pragma unroll
+                    for (int c = 1; c <= R - 4; ++c) prefix += V[dd][c];
+                    cost[0] = (all4 + from_left(all4)) + (from_left(from_left(suffix2)) + from_right(prefix));
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        // slide as below: the dropped column is the minuend (see the DPP note there)
+                        const int drop = c - R, take = c + 1 + R;
+                        const unsigned tk = take <= 7 ? from_right(V[dd][take - 4])
+                                                      : from_right(from_right(V[dd][take - 8]));
+                        unsigned n = (drop >= -4 ? from_left(V[dd][drop + 4])
+                                                 : from_left(from_left(V[dd][drop + 8]))) - cost[c];
+                        asm volatile("" : "+v"(n));
+                        cost[c + 1] = tk - n;
+                    }
                 } else {
                     // cost[c] = sum of V over columns c-R .. c+R; columns < 0 live in the
                     // left neighbour lane (as its column +4), columns > 3 in the right one
@@ -721,18 +746,20 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
 
     const int r = win / 2;
     const int D = max_disp < w ? max_disp : w;  // candidates beyond column 0 do not exist
-    if (r <= 4 && D <= 4096 && !ctx->force_bruteforce) {
+    const bool ssd = cost_mode == STX_COST_SSD && r > 0;  // a single tap orders candidates as SAD does
+    if (r <= (ssd ? 5 : 6) && D <= 4096 && !ctx->force_bruteforce) {
         BandArgs a;
         a.img0 = d_img0; a.img1 = d_img1; a.w = w; a.h = h; a.stride = stride;
         a.pair_stride = pair_stride; a.row0 = row0; a.rows = rows; a.bh = rows; a.D = D;
         a.dbase = 0; a.keys = nullptr; a.first_pass = 1; a.last_pass = 1; a.out = o;
         a.out_stride = out_stride; a.out_pair_stride = out_pair_stride; a.out_bytes = out_bytes;
-        if (cost_mode == STX_COST_SSD && r > 0) {  // a single tap orders candidates as SAD does
+        if (ssd) {
             switch (r) {
             case 1: return launch_band<1, true>(ctx, a, n_pairs);
             case 2: return launch_band<2, true>(ctx, a, n_pairs);
             case 3: return launch_band<3, true>(ctx, a, n_pairs);
-            default: return launch_band<4, true>(ctx, a, n_pairs);
+            case 4: return launch_band<4, true>(ctx, a, n_pairs);
+            default: return launch_band<5, true>(ctx, a, n_pairs);
             }
         }
         switch (r) {
@@ -740,7 +767,9 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
         case 1: return launch_band<1, false>(ctx, a, n_pairs);
         case 2: return launch_band<2, false>(ctx, a, n_pairs);
         case 3: return launch_band<3, false>(ctx, a, n_pairs);
-        default: return launch_band<4, false>(ctx, a, n_pairs);
+        case 4: return launch_band<4, false>(ctx, a, n_pairs);
+        case 5: return launch_band<5, false>(ctx, a, n_pairs);
+        default: return launch_band<6, false>(ctx, a, n_pairs);
         }
     }
     const size_t lds = (size_t)(EXT_TX + 2 * r) * (EXT_TY + 2 * r) +

@@ -81,7 +81,8 @@ def test_compute_depth_image_reference_signature(ctx, oracle):
 
 
 EXT_CASES = [(1, 1, 0), (1, 16, 0), (1, 64, 1), (3, 5, 0), (3, 16, 0), (5, 24, 0), (5, 16, 1),
-             (7, 33, 0), (9, 32, 0), (9, 64, 1), (11, 20, 0), (15, 40, 0), (9, 256, 0)]
+             (7, 33, 0), (9, 32, 0), (9, 64, 1), (11, 20, 0), (11, 48, 1), (13, 40, 0), (13, 24, 1),
+             (15, 40, 0), (9, 256, 0)]
 
 
 @pytest.mark.parametrize("algo", [api.DISP_AUTO, api.DISP_BRUTEFORCE])
@@ -98,7 +99,7 @@ def test_disparity_ext_matches_oracle(ctx, oracle, win, D, cm, algo):
     assert (got == want).all(), np.argwhere(got != want)[:10]
 
 
-@pytest.mark.parametrize("win", [1, 3, 5, 7, 9])
+@pytest.mark.parametrize("win", [1, 3, 5, 7, 9, 11, 13])
 @pytest.mark.parametrize("h,w,D", [(40, 300, 16), (130, 520, 100), (70, 777, 256), (33, 1100, 300),
                                    (20, 900, 700)])
 def test_disparity_sliding_kernel_tiles_and_passes(ctx, oracle, win, h, w, D):
@@ -111,7 +112,7 @@ def test_disparity_sliding_kernel_tiles_and_passes(ctx, oracle, win, h, w, D):
     assert (got == want).all(), np.argwhere(got != want)[:10]
 
 
-@pytest.mark.parametrize("win", [3, 5, 7, 9])
+@pytest.mark.parametrize("win", [3, 5, 7, 9, 11])
 @pytest.mark.parametrize("h,w,D", [(40, 300, 16), (60, 520, 100), (33, 777, 256), (25, 1100, 300),
                                    (20, 900, 700)])
 def test_disparity_sliding_kernel_ssd(ctx, oracle, win, h, w, D):
@@ -133,10 +134,12 @@ def test_disparity_ssd_extreme_contrast(ctx, oracle):
     a[5, 100] = 0
     b[7, 50:60] = 0
     b[:, 300:] = 255                      # exact matches (cost 0) far to the right
-    for cm in (api.COST_SAD, api.COST_SSD):
-        want = oracle.disparity_ext(a, b, 9, D, cm, np.uint16, sliding=True)
-        got = ctx.disparity(a, b, win=9, max_disp=D, cost_mode=cm, out_dtype=np.uint16)
-        assert (got == want).all(), (cm, np.argwhere(got != want)[:10])
+    # 11x11 (half-word SAD sums up to 255*121, SSD keys up to 65025*121 << 8) and 13x13 SAD as well
+    for win, cm in ((9, api.COST_SAD), (9, api.COST_SSD), (11, api.COST_SAD), (11, api.COST_SSD),
+                    (13, api.COST_SAD), (13, api.COST_SSD)):
+        want = oracle.disparity_ext(a, b, win, D, cm, np.uint16, sliding=True)
+        got = ctx.disparity(a, b, win=win, max_disp=D, cost_mode=cm, out_dtype=np.uint16)
+        assert (got == want).all(), (win, cm, np.argwhere(got != want)[:10])
 
 
 @pytest.mark.parametrize("h,w,win,D", [(1, 1, 3, 4), (2, 3, 5, 8), (5, 64, 9, 16), (17, 65, 9, 16),
