@@ -200,13 +200,13 @@ __global__ __launch_bounds__(EXT_THREADS) void disp_ext_bruteforce_kernel(
 
 
 // ---------------------------------------------------------------------------
-// D1-ext, sliding-sum kernel (SAD, window radius 0..6; SSD radius 1..5; any max_disp).
+// D1-ext, sliding-sum kernel (SAD, window radius 0..7; SSD radius 1..5; any max_disp).
 //
 // Work decomposition
 //   workgroup = one tile of 256 image columns x one band of `bh` output rows;
 //   wave w of the workgroup owns the 16 disparities d in [dbase+16w, dbase+16w+16);
 //   lane l of a wave owns the 4 adjacent columns x0+4l .. x0+4l+3.
-// Rows are streamed top to bottom through an LDS ring of BAND_RING rows.  A ring
+// Rows are streamed top to bottom through an LDS ring of band_ring(win) rows.  A ring
 // row holds the img0 row (256 columns), the img1 row (256 + 16*nw columns to the
 // left) and a candidate-validity mask row, all as 32-bit words with the pixel
 // value pre-shifted by BAND_SH bits, so that every cost this kernel forms is
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(EXT_THREADS) void disp_ext_bruteforce_kernel(
 // from registers filled by 128-bit LDS reads (one lane = 4 columns = one b128).
 // The horizontal window sum slides across the lane's 4 columns and takes the
 // columns it lacks from the neighbouring lanes with wave_shr:1 / wave_shl:1 DPP
-// adds (window radius <= 4 => one lane to each side; radius 5, 6 => two, with chained hops).  The key
+// adds (window radius <= 4 => one lane to each side; radius 5..7 => two, with chained hops).  The key
 //     (cost << BAND_SH) + (4095 - d) + mask(img1[y][x-d] == 0 or x-d < 0)
 // is reduced with v_min3_u32 over the wave's 16 disparities, then across the
 // workgroup's waves with one LDS atomic min per pixel: smallest cost wins, equal
@@ -226,7 +226,10 @@ __global__ __launch_bounds__(EXT_THREADS) void disp_ext_bruteforce_kernel(
 // first-wins order for an ascending-x1 scan.
 // ---------------------------------------------------------------------------
 
-constexpr int BAND_RING = 16;        // LDS ring rows; needs win + 2 <= BAND_RING
+// LDS ring rows for a window: win + 2 of them are live at once; 16 (a mask instead of a modulo)
+// up to 13x13, 20 for 15x15 (32 rows would not fit the LDS next to 16 waves' img1 columns)
+constexpr int band_ring(int win) { return win + 2 <= 16 ? 16 : 20; }
+template <int RING> __device__ __forceinline__ int band_slot(int yy) { return (yy + 4 * RING) % RING; }
 constexpr int BAND_ND = 16;          // disparities per wave
 constexpr int BAND_COLS = 256;       // columns per tile (64 lanes x 4)
 constexpr unsigned BAND_SH = 12;     // key = cost << 12 | (4095 - d)
@@ -380,19 +383,20 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     constexpr unsigned INIT = PK ? (((unsigned)(WIN * WIN * 255 + 1) << 16) - 1u) : SSD ? 0x7FFFFFFFu : BAND_INIT;
     constexpr int HL = (R + 3) / 4;  // halo lanes on each side of the tile
     constexpr int TILE_OUT = BAND_COLS - 8 * HL;
-    static_assert(WIN + 2 <= BAND_RING, "ring too small");
+    constexpr int RING = band_ring(WIN);
+    static_assert(WIN + 2 <= RING && RING >= 8, "ring too small");
 
     extern __shared__ u32x4 band_lds4[];
     const int nw = blockDim.x >> 6;
     const int rw4 = BAND_COLS / 4 + (BAND_ND / 4) * nw;  // img1 row length in 4-column groups
     const int rw = 4 * rw4;                              // img1 columns per ring row
     u32x4 *Lrow4 = band_lds4;                            // [RING][64]
-    u32x4 *Rrow4 = Lrow4 + BAND_RING * (BAND_COLS / 4);  // [RING][rw4]
-    u32x4 *Mrow4 = Rrow4 + BAND_RING * rw4;              // [RING][rw4]
+    u32x4 *Rrow4 = Lrow4 + RING * (BAND_COLS / 4);  // [RING][rw4]
+    u32x4 *Mrow4 = Rrow4 + RING * rw4;              // [RING][rw4]
     unsigned *Lrow = reinterpret_cast<unsigned *>(Lrow4);
     unsigned *Rrow = reinterpret_cast<unsigned *>(Rrow4);
     unsigned *Mrow = reinterpret_cast<unsigned *>(Mrow4);
-    unsigned *best = reinterpret_cast<unsigned *>(Mrow4 + BAND_RING * rw4);  // [2][256]
+    unsigned *best = reinterpret_cast<unsigned *>(Mrow4 + RING * rw4);  // [2][256]
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
         }
     };
     auto fill_store = [&](int yy) {
-        const int slot = (yy + 64) & (BAND_RING - 1);
+        const int slot = band_slot<RING>(yy);
         if (tid < BAND_COLS) Lrow[slot * BAND_COLS + tid] = fill_l << PSH;
 #pragma unroll
         for (int k = 0; k < FILL_MAX; ++k) {
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
 
         // ---- add the row entering the window --------------------------------
         if (active) {
-            const int slot = (ys + 64) & (BAND_RING - 1);
+            const int slot = band_slot<RING>(ys);
             unsigned rv[20], lv[4];
             lds_read_1_5(Lrow4 + slot * (BAND_COLS / 4) + lane, Rrow4 + slot * rw4 + roff4, lv, rv);
             if constexpr (PK) {
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
         }
         // ---- subtract the row leaving the window ----------------------------
         if (active && R > 0 && ys - WIN >= ys0) {
-            const int slot = (ys - WIN + 64) & (BAND_RING - 1);
+            const int slot = band_slot<RING>(ys - WIN);
             unsigned rv[20], lv[4];
             lds_read_1_5(Lrow4 + slot * (BAND_COLS / 4) + lane, Rrow4 + slot * rw4 + roff4, lv, rv);
             if constexpr (PK) {
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
         // ---- output row y = ys - R: window sums, keys, winner-take-all --------
         const int y = ys - R;
         if (active && y >= yb) {
-            const int slot = (y + 64) & (BAND_RING - 1);
+            const int slot = band_slot<RING>(y);
             unsigned mv[20];
             lds_read_5(Mrow4 + slot * rw4 + roff4, mv);
             unsigned m[4] = {~0u, ~0u, ~0u, ~0u};
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
 #pragma unroll
                     for (int c = 0; c < 4; ++c) cost[c] = W1[dd][c];
                 } else if constexpr (R > 4) {
-                    // R = 5, 6: the window spans two lanes to each side.  cost[0] = this lane's
+                    // R = 5..7: the window spans two lanes to each side.  cost[0] = this lane's
                     // and the left lane's four columns, columns 8-R..3 of the lane two to the
                     // left and columns 0..R-4 of the right lane
                     const unsigned all4 = (V[dd][0] + V[dd][1]) + (V[dd][2] + V[dd][3]);
@@ -650,7 +654,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
                     emit = a.last_pass;
                 }
                 if (emit) {
-                    const int slot = (y + 64) & (BAND_RING - 1);
+                    const int slot = band_slot<RING>(y);
                     int v;
                     if (Lrow[slot * BAND_COLS + c] == 0)
                         v = 0;  // centre pixel of img0 is 0: output stays 0
@@ -708,7 +712,7 @@ int launch_band(stx_ctx *ctx, BandArgs a, int n_pairs)
         a.first_pass = p == 0;
         a.last_pass = p == npass - 1;
         const int rw = BAND_COLS + BAND_ND * nw;
-        const size_t lds = sizeof(unsigned) * ((size_t)BAND_RING * (BAND_COLS + 2 * rw) + 2 * BAND_COLS);
+        const size_t lds = sizeof(unsigned) * ((size_t)band_ring(2 * R + 1) * (BAND_COLS + 2 * rw) + 2 * BAND_COLS);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(disp_band_kernel<R, SSD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -747,7 +751,7 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
     const int r = win / 2;
     const int D = max_disp < w ? max_disp : w;  // candidates beyond column 0 do not exist
     const bool ssd = cost_mode == STX_COST_SSD && r > 0;  // a single tap orders candidates as SAD does
-    if (r <= (ssd ? 5 : 6) && D <= 4096 && !ctx->force_bruteforce) {
+    if (r <= (ssd ? 5 : 7) && D <= 4096 && !ctx->force_bruteforce) {
         BandArgs a;
         a.img0 = d_img0; a.img1 = d_img1; a.w = w; a.h = h; a.stride = stride;
         a.pair_stride = pair_stride; a.row0 = row0; a.rows = rows; a.bh = rows; a.D = D;
@@ -769,7 +773,8 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
         case 3: return launch_band<3, false>(ctx, a, n_pairs);
         case 4: return launch_band<4, false>(ctx, a, n_pairs);
         case 5: return launch_band<5, false>(ctx, a, n_pairs);
-        default: return launch_band<6, false>(ctx, a, n_pairs);
+        case 6: return launch_band<6, false>(ctx, a, n_pairs);
+        default: return launch_band<7, false>(ctx, a, n_pairs);
         }
     }
     const size_t lds = (size_t)(EXT_TX + 2 * r) * (EXT_TY + 2 * r) +

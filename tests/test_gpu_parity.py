@@ -99,7 +99,7 @@ def test_disparity_ext_matches_oracle(ctx, oracle, win, D, cm, algo):
     assert (got == want).all(), np.argwhere(got != want)[:10]
 
 
-@pytest.mark.parametrize("win", [1, 3, 5, 7, 9, 11, 13])
+@pytest.mark.parametrize("win", [1, 3, 5, 7, 9, 11, 13, 15])
 @pytest.mark.parametrize("h,w,D", [(40, 300, 16), (130, 520, 100), (70, 777, 256), (33, 1100, 300),
                                    (20, 900, 700)])
 def test_disparity_sliding_kernel_tiles_and_passes(ctx, oracle, win, h, w, D):
@@ -136,7 +136,7 @@ def test_disparity_ssd_extreme_contrast(ctx, oracle):
     b[:, 300:] = 255                      # exact matches (cost 0) far to the right
     # 11x11 (half-word SAD sums up to 255*121, SSD keys up to 65025*121 << 8) and 13x13 SAD as well
     for win, cm in ((9, api.COST_SAD), (9, api.COST_SSD), (11, api.COST_SAD), (11, api.COST_SSD),
-                    (13, api.COST_SAD), (13, api.COST_SSD)):
+                    (13, api.COST_SAD), (13, api.COST_SSD), (15, api.COST_SAD)):
         want = oracle.disparity_ext(a, b, win, D, cm, np.uint16, sliding=True)
         got = ctx.disparity(a, b, win=win, max_disp=D, cost_mode=cm, out_dtype=np.uint16)
         assert (got == want).all(), (win, cm, np.argwhere(got != want)[:10])
