@@ -177,12 +177,13 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_error_kernel(
     errors[o] = sqrtf(dot3(w0, w1, w2, w0, w1, w2));
 }
 
-// One wave per hypothesis: localInliers and the running avgError of :232-236.  fp32 addition
-// does not reassociate, so the sum is a serial chain in pair order -- but only the inliers are
-// on it.  Per tile of RD_TILE errors the wave (a) compacts the inliers, in order, into LDS with
-// ballot / mbcnt prefix counts, all lanes working, then (b) runs the chain over the compacted
-// values, every lane redundantly, sixteen values per step with the next step's LDS reads in flight.  The
-// next tile's global loads are issued before (b), so the chain never waits on HBM.
+// One workgroup of two waves per hypothesis: localInliers and the running avgError of :232-236.
+// fp32 addition does not reassociate, so the sum is a serial chain in pair order -- but only the
+// inliers are on it.  Per tile of RD_TILE errors (a) one wave compacts the inliers, in order,
+// into LDS with ballot / mbcnt prefix counts, all lanes working, while (b) the other wave runs
+// the chain over the previous tile's compacted values, every lane redundantly, sixteen values
+// per step with the next step's LDS reads in flight.  The next tile's global loads are issued
+// before (a), so neither wave waits on HBM once the pipeline runs.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // (`sum` is tied into both asm blocks so that the adds between them stay between them)
@@ -211,64 +212,83 @@ __device__ __forceinline__ void chain16(float &sum, const f32x4 &v0, const f32x4
 constexpr int RD_K = 8;               // values per lane per tile
 constexpr int RD_TILE = 64 * RD_K;
 
-__global__ __launch_bounds__(64) void ransac_reduce_kernel(const float *__restrict__ errors, int n, float threshold,
-                                                           int32_t *__restrict__ inliers,
-                                                           float *__restrict__ err_sum)
+__global__ __launch_bounds__(128) void ransac_reduce_kernel(const float *__restrict__ errors, int n, float threshold,
+                                                            int32_t *__restrict__ inliers,
+                                                            float *__restrict__ err_sum)
 {
-    __shared__ __align__(16) float list[RD_TILE + 32];
-    const int h = blockIdx.x, lane = threadIdx.x;
+    // two waves per hypothesis: wave 1 compacts tile t into list[t & 1] while wave 0 runs the
+    // chain over tile t - 1 in the other buffer; one barrier per tile
+    __shared__ __align__(16) float list[2][RD_TILE + 32];
+    __shared__ int fill[2];
+    const int h = blockIdx.x, lane = threadIdx.x & 63;
+    const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 1;
     const float *e = errors + (size_t)h * n;
-    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) float *)list;
+    const int tiles = (n + RD_TILE - 1) / RD_TILE;
     float sum = 0.0f;
     int count = 0;
     float next[RD_K];
-#pragma unroll
-    for (int k = 0; k < RD_K; ++k) {
-        const int j = k * 64 + lane;
-        next[k] = j < n ? e[j] : -1.0f;
-    }
-    for (int base = 0; base < n; base += RD_TILE) {
-        float cur[RD_K];
-#pragma unroll
-        for (int k = 0; k < RD_K; ++k) cur[k] = next[k];
+    if (producer) {
 #pragma unroll
         for (int k = 0; k < RD_K; ++k) {
-            const int j = base + RD_TILE + k * 64 + lane;
+            const int j = k * 64 + lane;
             next[k] = j < n ? e[j] : -1.0f;
         }
-        // (a) in-order compaction of this tile's inliers
-        int m = 0;
+    }
+    for (int t = 0; t <= tiles; ++t) {
+        if (producer) {
+            if (t < tiles) {
+                float cur[RD_K];
 #pragma unroll
-        for (int k = 0; k < RD_K; ++k) {
-            const bool in = cur[k] >= 0.0f && cur[k] < threshold;
-            const unsigned long long mask = __ballot(in);
-            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-            if (in) list[m + before] = cur[k];
-            m += __popcll(mask);
+                for (int k = 0; k < RD_K; ++k) cur[k] = next[k];
+#pragma unroll
+                for (int k = 0; k < RD_K; ++k) {
+                    const int j = (t + 1) * RD_TILE + k * 64 + lane;
+                    next[k] = j < n ? e[j] : -1.0f;
+                }
+                // (a) in-order compaction of this tile's inliers
+                float *dst = list[t & 1];
+                int m = 0;
+#pragma unroll
+                for (int k = 0; k < RD_K; ++k) {
+                    const bool in = cur[k] >= 0.0f && cur[k] < threshold;
+                    const unsigned long long mask = __ballot(in);
+                    const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                    if (in) dst[m + before] = cur[k];
+                    m += __popcll(mask);
+                }
+                // whole groups are read; a group past the end is all +0, which leaves the
+                // (non-negative) sum as it is
+                if (lane < 32) dst[m + lane] = 0.0f;
+                if (lane == 0) fill[t & 1] = m;
+            }
+        } else if (t > 0) {
+            // (b) the chain, 16 values per group.  The next group's four LDS reads are issued
+            // BEFORE the current group's adds and waited for after them: written as asm because
+            // the compiler otherwise sinks the reads to their uses and every group pays the LDS
+            // round trip.
+            const int m = fill[(t - 1) & 1];
+            if (m > 0) {
+                const unsigned lbase =
+                    (unsigned)(size_t)(__attribute__((address_space(3))) float *)list[(t - 1) & 1];
+                const int groups = (m + 15) >> 4;
+                f32x4 a0, a1, a2, a3, b0, b1, b2, b3;
+                lds_issue4(lbase, a0, a1, a2, a3, sum);
+                lds_wait(a0, a1, a2, a3, sum);
+                for (int g = 0; g < groups; g += 2) {
+                    lds_issue4(lbase + 64u * (unsigned)min(g + 1, groups), b0, b1, b2, b3, sum);
+                    chain16(sum, a0, a1, a2, a3);
+                    lds_wait(b0, b1, b2, b3, sum);
+                    lds_issue4(lbase + 64u * (unsigned)min(g + 2, groups), a0, a1, a2, a3, sum);
+                    chain16(sum, b0, b1, b2, b3);
+                    lds_wait(a0, a1, a2, a3, sum);
+                }
+                count += m;
+            }
         }
-        if (m == 0) continue;
-        if (lane < 32) list[m + lane] = 0.0f;  // whole groups are read; a group past the end is all +0,
-        __syncthreads();                       // which leaves the (non-negative) sum as it is
-        // (b) the chain, 16 values per group.  The next group's four LDS reads are issued BEFORE
-        // the current group's adds and waited for after them: written as asm because the compiler
-        // otherwise sinks the reads to their uses and every group pays the LDS round trip.
-        const int groups = (m + 15) >> 4;
-        f32x4 a0, a1, a2, a3, b0, b1, b2, b3;
-        lds_issue4(lbase, a0, a1, a2, a3, sum);
-        lds_wait(a0, a1, a2, a3, sum);
-        for (int g = 0; g < groups; g += 2) {
-            lds_issue4(lbase + 64u * (unsigned)min(g + 1, groups), b0, b1, b2, b3, sum);
-            chain16(sum, a0, a1, a2, a3);
-            lds_wait(b0, b1, b2, b3, sum);
-            lds_issue4(lbase + 64u * (unsigned)min(g + 2, groups), a0, a1, a2, a3, sum);
-            chain16(sum, b0, b1, b2, b3);
-            lds_wait(a0, a1, a2, a3, sum);
-        }
-        count += m;
         __syncthreads();
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         inliers[h] = count;
         err_sum[h] = sum;
     }
@@ -325,7 +345,7 @@ int stx_launch_ransac_score(stx_ctx *ctx, const float *hyp, int n_hyp, const flo
                            d_errors, reinterpret_cast<float2 *>(d_depths));
         STX_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(ransac_reduce_kernel, dim3((unsigned)n_hyp), dim3(64), 0, ctx->stream, d_errors, n, threshold,
+    hipLaunchKernelGGL(ransac_reduce_kernel, dim3((unsigned)n_hyp), dim3(128), 0, ctx->stream, d_errors, n, threshold,
                        d_inliers, d_err_sum);
     return (int)hipGetLastError();
 }
