@@ -304,6 +304,24 @@ class Context:
             out += (depths,)
         return out
 
+    def triangulate(self, E, R, t, K_x, K_xprime, x, xprime, decomposed=True):
+        """Triangulate (stereo/Stereography.cpp:383-443) for every pair at once, as the depth loop of
+        main.cpp:289-316 calls it: pointX = K_x^-1 (x, 1), pointXPrime = K_xprime^-1 (xprime, 1),
+        LindstromOptimisation with E, then the two ray depths with R, t = the outputs of
+        DecomposeEssentialMatrix(E, R_other, R, t) (main.cpp:285 / Stereography.cpp:398), which
+        stay with the caller.  Returns (depth0 [n], depth1 [n]) float32, NaN where Triangulate
+        returns false.  (The reference's Triangulate also rescales the shared E in place on every
+        call, :318, which moves E by an ulp or two from pair to pair; here every pair sees the E
+        passed in.)"""
+        rec = np.zeros((1, HYP_FLOATS), np.float32)
+        rec[0, 0:9] = np.asarray(E, np.float32).reshape(9)
+        rec[0, 9:18] = np.eye(3, dtype=np.float32).reshape(9)   # ReprojectionError's R, t: unused here
+        rec[0, 21:30] = np.asarray(R, np.float32).reshape(9)
+        rec[0, 30:33] = np.asarray(t, np.float32).reshape(3)
+        rec[0, 33] = 1.0 if decomposed else 0.0
+        _, _, depths = self.ransac_score(rec, K_x, K_xprime, x, xprime, want_depths=True)
+        return depths[0, :, 0].copy(), depths[0, :, 1].copy()
+
     def ransac_score_dev(self, hyp, K1, K2, p1, p2, exclude, threshold, inliers, err_sum, errors=None, depths=None):
         """Device tensors: p1, p2 [n,2] float32, inliers [H] int32, err_sum [H] float32, errors
         [H,n] / depths [H,n,2] float32 or None; hyp [H,36], K1, K2, exclude [H,8] host arrays."""

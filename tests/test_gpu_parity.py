@@ -1052,3 +1052,48 @@ def test_ransac_golden_vectors_gpu(ctx):
                                           want_errors=True, want_depths=True)
     assert inl.tolist() == g["inliers"].tolist() and _same_f32(tot, g["err_sum"])
     assert _same_f32(err, g["errors"]) and _same_f32(dep, g["depths"])
+
+
+def test_triangulated_depths(ctx, oracle):
+    """north_star: triangulated depths within 1e-4 relative.  Exact correspondences of a known
+    two-view geometry X2 = R X1 + t: Triangulate's depths are the lengths of the two rays (checked
+    against float64 geometry to 1e-4), and bit-equal to the oracle's Triangulate."""
+    import ctypes as C
+    rng = np.random.RandomState(17)
+    n = 5000
+    ang = np.deg2rad(2.5)
+    r = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t = np.array([-0.6, 0.02, 0.05])
+    t = t / np.linalg.norm(t)
+    k1 = np.array([[2592.0, 0, 1440], [0, 2592, 994], [0, 0, 1]])
+    k2 = np.array([[2618.0, 0, 1447], [0, 2618, 990], [0, 0, 1]])
+    x1 = np.stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(4, 15, n)], axis=1)
+    x2 = (r @ x1.T).T + t
+    p1 = (k1 @ x1.T).T
+    p2 = (k2 @ x2.T).T
+    p1 = np.ascontiguousarray(p1[:, :2] / p1[:, 2:], np.float32)
+    p2 = np.ascontiguousarray(p2[:, :2] / p2[:, 2:], np.float32)
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    # the reference evaluates x^T E x' with x from the first camera (Stereography.cpp:368)
+    e = np.ascontiguousarray((tx @ r).T, np.float32)
+    rf, tf = np.ascontiguousarray(r, np.float32), np.ascontiguousarray(t, np.float32)
+    d0, d1 = ctx.triangulate(e, rf, tf, k1.astype(np.float32), k2.astype(np.float32), p1, p2)
+    want0, want1 = np.linalg.norm(x1, axis=1), np.linalg.norm(x2, axis=1)
+    # pixel coordinates rounded to fp32 (about 1e-4 px) move a depth by a few 1e-6 relative
+    assert np.abs(d0 / want0 - 1).max() < 1e-4 and np.abs(d1 / want1 - 1).max() < 1e-4
+    # bit-exact against the oracle's Triangulate on the same rays
+    k1i, k2i = oracle.invert3x3(k1.astype(np.float32)), oracle.invert3x3(k2.astype(np.float32))
+    f = oracle.lib().oracle_triangulate
+    for i in range(0, n, 97):
+        a = np.array([p1[i, 0], p1[i, 1], 1], np.float32)
+        b = np.array([p2[i, 0], p2[i, 1], 1], np.float32)
+        x = np.array([k1i[j, 0] * a[0] + (k1i[j, 1] * a[1] + k1i[j, 2] * a[2]) for j in range(3)], np.float32)
+        xp = np.array([k2i[j, 0] * b[0] + (k2i[j, 1] * b[1] + k2i[j, 2] * b[2]) for j in range(3)], np.float32)
+        o0, o1 = C.c_float(0), C.c_float(0)
+        assert f(C.byref(o0), C.byref(o1), C.c_void_p(x.ctypes.data), C.c_void_p(xp.ctypes.data),
+                 C.c_void_p(e.ctypes.data), C.c_void_p(rf.ctypes.data), C.c_void_p(tf.ctypes.data), 1) == 1
+        assert np.float32(o0.value) == d0[i] and np.float32(o1.value) == d1[i]
+    # a failed decomposition (Triangulate returns false, :398-401) gives NaN depths
+    n0, n1 = ctx.triangulate(e, rf, tf, k1.astype(np.float32), k2.astype(np.float32), p1[:5], p2[:5],
+                             decomposed=False)
+    assert np.isnan(n0).all() and np.isnan(n1).all()
