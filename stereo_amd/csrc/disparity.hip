@@ -492,27 +492,47 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
             lds_read_1_5(Lrow4 + slot * (BAND_COLS / 4) + lane, Rrow4 + slot * rw4 + roff4, lv, rv);
             if constexpr (PK) {
 #pragma unroll
-                for (int pp = 0; pp < BAND_ND / 2; ++pp)
+                for (int pp = 0; pp < BAND_ND / 2; ++pp) {
+                    // four independent instructions, then their four dependants: on gfx950 a
+                    // VALU instruction that reads a v_sad_* result right behind it costs a wait
+                    // state (the compiler pads with s_nop), 64 of them per row in the paired form
+                    unsigned t[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const unsigned t = sad_u8(rv[16 + c - pp], lv[c], V[pp][c]);
-                        V[pp][c] = sad_hi_u8(rv[16 + c - pp - BAND_ND / 2], lv[c], t);
-                    }
+                    for (int c = 0; c < 4; ++c) t[c] = sad_u8(rv[16 + c - pp], lv[c], V[pp][c]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) V[pp][c] = sad_hi_u8(rv[16 + c - pp - BAND_ND / 2], lv[c], t[c]);
+                }
             } else
 #pragma unroll
-            for (int dd = 0; dd < BAND_ND; ++dd)
+            for (int d2 = 0; d2 < BAND_ND; d2 += 2) {
+                // eight independent instructions, then their eight dependants (see the PK branch)
+                unsigned sum[2][4];
+                if (SSD) {
+                    unsigned t[2][4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    unsigned sum;
-                    if (SSD)
-                        sum = sq_acc_u24(sad_u32_0(rv[16 + c - dd], lv[c]), V[dd][c]);
-                    else
-                        sum = sad_u32(rv[16 + c - dd], lv[c], V[dd][c]);
-                    if (R == 0)  // 1x1 window: the sum is one term; V only holds the code
-                        W1[dd][c] = sum;
-                    else
-                        V[dd][c] = sum;
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) t[q][c] = sad_u32_0(rv[16 + c - d2 - q], lv[c]);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) sum[q][c] = sq_acc_u24(t[q][c], V[d2 + q][c]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) sum[q][c] = sad_u32(rv[16 + c - d2 - q], lv[c], V[d2 + q][c]);
                 }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (R == 0)  // 1x1 window: the sum is one term; V only holds the code
+                            W1[d2 + q][c] = sum[q][c];
+                        else
+                            V[d2 + q][c] = sum[q][c];
+                    }
+            }
         }
         // ---- subtract the row leaving the window ----------------------------
         if (active && R > 0 && ys - WIN >= ys0) {
@@ -521,20 +541,34 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
             lds_read_1_5(Lrow4 + slot * (BAND_COLS / 4) + lane, Rrow4 + slot * rw4 + roff4, lv, rv);
             if constexpr (PK) {
 #pragma unroll
-                for (int pp = 0; pp < BAND_ND / 2; ++pp)
+                for (int pp = 0; pp < BAND_ND / 2; ++pp) {
+                    unsigned t[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const unsigned t = sad_u8_0(rv[16 + c - pp], lv[c]);
-                        V[pp][c] -= sad_hi_u8(rv[16 + c - pp - BAND_ND / 2], lv[c], t);
-                    }
+                    for (int c = 0; c < 4; ++c) t[c] = sad_u8_0(rv[16 + c - pp], lv[c]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) t[c] = sad_hi_u8(rv[16 + c - pp - BAND_ND / 2], lv[c], t[c]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) V[pp][c] -= t[c];
+                }
             } else
 #pragma unroll
-            for (int dd = 0; dd < BAND_ND; ++dd)
+            for (int d2 = 0; d2 < BAND_ND; d2 += 2) {
+                unsigned t[2][4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const unsigned t = sad_u32_0(rv[16 + c - dd], lv[c]);
-                    V[dd][c] -= SSD ? sq_u24(t) : t;
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) t[q][c] = sad_u32_0(rv[16 + c - d2 - q], lv[c]);
+                if (SSD) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) t[q][c] = sq_u24(t[q][c]);
                 }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) V[d2 + q][c] -= t[q][c];
+            }
         }
 
         // ---- output row y = ys - R: window sums, keys, winner-take-all --------
