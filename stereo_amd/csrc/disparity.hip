@@ -419,19 +419,35 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     // ---- ring fill: one image row -> slot ---------------------------------
     // each thread carries at most FILL_MAX words between its global loads (issued
     // at the top of a step) and its LDS stores (issued just before the barrier)
+    // Loads go through buffer descriptors over the pair's two images: the column is a 32-bit
+    // offset fixed per thread (0x80000000, which the range check turns into a zero, for columns
+    // outside the image or beyond this thread's share), the row a scalar offset -- no per-row
+    // 64-bit address arithmetic.  (The launcher keeps one image below 2 GiB.)
     constexpr int FILL_MAX = 2;
     unsigned fill_l = 0, fill_r[FILL_MAX] = {0, 0};
-    auto fill_load = [&](int yy) {
-        const bool rowok = yy >= 0 && yy < h;
-        if (tid < BAND_COLS) {
-            const int x = x0 + tid;
-            fill_l = (rowok && x >= 0 && x < w) ? i0[(size_t)yy * a.stride + x] : 0u;
-        }
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(i0), 0, (int)((unsigned)a.stride * (unsigned)h), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(i1), 0, (int)((unsigned)a.stride * (unsigned)h), 0x00020000);
+    constexpr unsigned FILL_NONE = 0x80000000u;
+    unsigned col_l = FILL_NONE, col_r[FILL_MAX];
+    if (tid < BAND_COLS && x0 + tid >= 0 && x0 + tid < w) col_l = (unsigned)(x0 + tid);
 #pragma unroll
-        for (int k = 0; k < FILL_MAX; ++k) {
-            const int i = tid + k * (int)blockDim.x;
-            const int x = rbase + i;
-            fill_r[k] = (i < rw && rowok && x >= 0 && x < w) ? i1[(size_t)yy * a.stride + x] : 0u;
+    for (int k = 0; k < FILL_MAX; ++k) {
+        const int i = tid + k * (int)blockDim.x;
+        const int x = rbase + i;
+        col_r[k] = (i < rw && x >= 0 && x < w) ? (unsigned)x : FILL_NONE;
+    }
+    auto fill_load = [&](int yy) {
+        if (yy >= 0 && yy < h) {  // uniform
+            const int rowoff = yy * (int)a.stride;
+            fill_l = __builtin_amdgcn_raw_buffer_load_b8(rs0, col_l, rowoff, 0);
+#pragma unroll
+            for (int k = 0; k < FILL_MAX; ++k) fill_r[k] = __builtin_amdgcn_raw_buffer_load_b8(rs1, col_r[k], rowoff, 0);
+        } else {
+            fill_l = 0;
+#pragma unroll
+            for (int k = 0; k < FILL_MAX; ++k) fill_r[k] = 0;
         }
     };
     auto fill_store = [&](int yy) {
@@ -785,7 +801,8 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
     const int r = win / 2;
     const int D = max_disp < w ? max_disp : w;  // candidates beyond column 0 do not exist
     const bool ssd = cost_mode == STX_COST_SSD && r > 0;  // a single tap orders candidates as SAD does
-    if (r <= (ssd ? 5 : 7) && D <= 4096 && !ctx->force_bruteforce) {
+    // (the band kernel addresses an image through 32-bit buffer offsets: one image below 2 GiB)
+    if (r <= (ssd ? 5 : 7) && D <= 4096 && !ctx->force_bruteforce && (unsigned long long)stride * (unsigned)h < (1ull << 31)) {
         BandArgs a;
         a.img0 = d_img0; a.img1 = d_img1; a.w = w; a.h = h; a.stride = stride;
         a.pair_stride = pair_stride; a.row0 = row0; a.rows = rows; a.bh = rows; a.D = D;
