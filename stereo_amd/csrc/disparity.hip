@@ -332,13 +332,13 @@ __device__ __forceinline__ void lds_read_1_5(const u32x4 *q, const u32x4 *p, uns
 __device__ __forceinline__ unsigned from_left(unsigned v)
 {
     // lane l receives lane l-1's value (wave_shr:1); folded into the consuming add
-    unsigned r = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+    unsigned r = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
     return r;
 }
 __device__ __forceinline__ unsigned from_right(unsigned v)
 {
     // lane l receives lane l+1's value (wave_shl:1)
-    unsigned r = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+    unsigned r = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
     return r;
 }
 
