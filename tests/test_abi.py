@@ -44,6 +44,17 @@ def test_null_context_is_rejected_without_touching_a_gpu():
     assert lib.stx_set_match_algo(None, 0) == -1
     assert lib.stx_disparity_u8(None, None, None, 4, 4, 4, 1, 0, 0, None, 4) == -1
     assert lib.stx_match(None, None, None, 0, None, None, 0, C.c_float(1.0), None, None, None, None, None) == -1
+    # the widened rows: every entry point checks its context before any HIP call
+    assert lib.stx_fast_detect_u8(None, None, 4, 4, 4, 30, None, 0, None) == -1
+    assert lib.stx_score_cluster(None, None, None, 4, 4, 4, None, 0, None, C.c_float(700), C.c_float(2), None, None,
+                                 None, None) == -1
+    assert lib.stx_cluster_features(None, None, None, 0, 2, None, None) == -1
+    assert lib.stx_sift_descriptors(None, None, None, 4, 4, 4, None, 0, None, None) == -1
+    assert lib.stx_ransac_score(None, None, 0, None, None, None, None, 0, None, C.c_float(70), None, None, None,
+                                None) == -1
+    assert lib.stx_ransac_score_dev(None, None, 0, None, None, None, None, 0, None, C.c_float(70), None, None, None,
+                                    None) == -1
+    assert lib.stx_rectify_disparity_u8(None, None, None, 4, 4, 4, None, None, 1, 0, 0, None, 4, None, None, 4) == -1
 
 
 def test_invert_homography_matches_oracle_bit_for_bit(oracle):

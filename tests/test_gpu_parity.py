@@ -1097,3 +1097,27 @@ def test_triangulated_depths(ctx, oracle):
     n0, n1 = ctx.triangulate(e, rf, tf, k1.astype(np.float32), k2.astype(np.float32), p1[:5], p2[:5],
                              decomposed=False)
     assert np.isnan(n0).all() and np.isnan(n1).all()
+
+
+def test_ransac_score_rejects_bad_arguments(ctx):
+    import ctypes as C
+    lib, h = ctx._lib, ctx._h
+    rec = np.zeros((1, 36), np.float32)
+    k = np.eye(3, dtype=np.float32)
+    p = np.zeros((4, 2), np.float32)
+    inl = np.zeros(1, np.int32)
+    tot = np.zeros(1, np.float32)
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    thr = C.c_float(70)
+    ok = lib.stx_ransac_score(h, vp(rec), 1, vp(k), vp(k), vp(p), vp(p), 4, None, thr, vp(inl), vp(tot), None, None)
+    assert ok == 0
+    assert lib.stx_ransac_score(h, vp(rec), 65536, vp(k), vp(k), vp(p), vp(p), 4, None, thr, vp(inl), vp(tot), None, None) == -1
+    assert lib.stx_ransac_score(h, vp(rec), -1, vp(k), vp(k), vp(p), vp(p), 4, None, thr, vp(inl), vp(tot), None, None) == -1
+    assert lib.stx_ransac_score(h, vp(rec), 1, vp(k), vp(k), vp(p), vp(p), -4, None, thr, vp(inl), vp(tot), None, None) == -1
+    assert lib.stx_ransac_score(h, None, 1, vp(k), vp(k), vp(p), vp(p), 4, None, thr, vp(inl), vp(tot), None, None) == -1
+    assert lib.stx_ransac_score(h, vp(rec), 1, None, vp(k), vp(p), vp(p), 4, None, thr, vp(inl), vp(tot), None, None) == -1
+    assert lib.stx_ransac_score(h, vp(rec), 1, vp(k), vp(k), None, vp(p), 4, None, thr, vp(inl), vp(tot), None, None) == -1
+    assert lib.stx_ransac_score(h, vp(rec), 1, vp(k), vp(k), vp(p), vp(p), 4, None, thr, None, vp(tot), None, None) == -1
+    # no pairs: pointers to them may be NULL
+    assert lib.stx_ransac_score(h, vp(rec), 1, vp(k), vp(k), None, None, 0, None, thr, vp(inl), vp(tot), None, None) == 0
+    assert inl[0] == 0 and tot[0] == 0
