@@ -210,6 +210,13 @@ def main():
                          "peak": VALU_LANEOPS / 1e12, "unit": "Tlane-op/s",
                          "frac": units * OPS_PER_UNIT_WINDOWED / (ms * 1e-3) / VALU_LANEOPS},
         }
+        # larger SAD windows through the same sliding-sum kernel (two halo lanes per side)
+        for wl in (11, 13, 15):
+            ms = event_time_ms(torch, lambda: ctx.disparity_dev(d_l, d_r, d_o, win=wl, max_disp=D), ks, kw)
+            extra["disparity_sad_%dx%d_d256" % (wl, wl)] = {
+                "workload": "%dx%d, %dx%d SAD window, %d disparities" % (W, H, wl, wl, D),
+                "ms": ms, "Mpix_disp_per_s": units / (ms * 1e-3) / 1e6,
+            }
         # BASELINE config 3: one 4K pair, 512 disparities (two passes, u16 output)
         w3, h3, D3 = 3840, 2160, 512
         l3, r3 = synth.rectified_pair(303, h3, w3, D3)
