@@ -372,9 +372,15 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     // of disparities.  key = cost << 16 | (65535 - d).  Disparities past D start from PK_PAST per
     // column, which lifts their costs above every valid one (PK_PAST > 255 * WIN) without
     // leaving the half-word (WIN * (PK_PAST + 255 * WIN) < 65536).
-    constexpr bool PK = !SSD && R > 0 && R <= 5;
-    constexpr unsigned PK_PAST = WIN <= 9 ? 3584u : 3000u;
-    static_assert(!PK || (PK_PAST > 255u * WIN && WIN * (PK_PAST + 255u * WIN) < 65536u), "half-word costs");
+    // 13x13 and 15x15 (PKW): costs reach 255 * 225 < 2^16, so a key may pass 2^31 and neither the
+    // bias nor bit 31 can mark an invalid candidate.  There the mask word saturates the cost field
+    // (0xFFFF0000) and a disparity past D carries an all-ones code, both above every valid key.
+    constexpr bool PK = !SSD && R > 0;
+    constexpr bool PKW = PK && R > 5;
+    constexpr unsigned PK_PAST = PKW ? 0u : WIN <= 9 ? 3584u : 3000u;
+    constexpr unsigned PK_MASKED = PKW ? 0xFFFF0000u : BAND_MASKED;
+    static_assert(!PK || PKW || (PK_PAST > 255u * WIN && WIN * (PK_PAST + 255u * WIN) < 65536u), "half-word costs");
+    static_assert(!PKW || 255u * WIN * WIN < 65535u, "half-word costs");
     static_assert(!SSD || (unsigned long long)WIN * WIN * 65025ull * 256ull < (1ull << 31), "SSD key width");
     constexpr unsigned SH = PK ? 16u : SSD ? 8u : BAND_SH;  // key = cost << SH | code
     constexpr unsigned PSH = PK ? 0u : SSD ? 4u : BAND_SH;  // pixel pre-shift in the ring
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
             const int i = tid + k * (int)blockDim.x;
             if (i < rw) {
                 Rrow[slot * rw + i] = fill_r[k] << PSH;
-                Mrow[slot * rw + i] = fill_r[k] ? 0u : BAND_MASKED;
+                Mrow[slot * rw + i] = fill_r[k] ? 0u : (PK ? PK_MASKED : BAND_MASKED);
             }
         }
     };
@@ -474,8 +480,8 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
 #pragma unroll
         for (int pp = 0; pp < BAND_ND / 2; ++pp) {
             const int dlo = dB + pp, dhi = dB + pp + BAND_ND / 2;
-            code_lo[pp] = LOW - (unsigned)dlo;
-            code_hi[pp] = LOW - (unsigned)dhi;
+            code_lo[pp] = PKW && dlo >= a.D ? ~0u : LOW - (unsigned)dlo;
+            code_hi[pp] = PKW && dhi >= a.D ? ~0u : LOW - (unsigned)dhi;
             const unsigned init = (dlo < a.D ? 0u : PK_PAST) | ((dhi < a.D ? 0u : PK_PAST) << 16);
 #pragma unroll
             for (int c = 0; c < 4; ++c) V[pp][c] = init;
