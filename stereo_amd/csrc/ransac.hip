@@ -11,8 +11,9 @@
 //
 // Arithmetic: fp32, every multiply, add, divide and sqrt its own correctly rounded operation
 // (-ffp-contract=off); three-term sums of fixed-size Eigen expressions as a0 + (a1 + a2), Eigen's
-// unrolled reduction (the order the rectification kernel already follows).  The error sum of a hypothesis is taken
-// in pair order by a serial chain (fp32 addition does not reassociate), one wave per hypothesis.
+// unrolled reduction (the order the rectification kernel already follows).  The error sum of a
+// hypothesis is taken in pair order by a serial chain (fp32 addition does not reassociate), one
+// workgroup of two waves per hypothesis.
 //
 // Bound: compute (about 30 IEEE divisions and square roots per evaluation); 16 B of pair data
 // in and 4 B of error out per evaluation.
