@@ -69,8 +69,8 @@ def units_evaluated(w, h, d):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary kernels")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--match-n", type=int, default=200000, help="n1 = n2 of the matching leg (BASELINE config 5)")
@@ -182,7 +182,7 @@ def main():
     extra = {}
     single = world == 1 and not args.no_extra
     if single:
-        ks, kw = max(3, args.steps // 4), 1
+        ks, kw = max(3, min(25, args.steps // 4)), 1
         # reference mode: 1x1 window, whole-row search (bit-exact vs the reference)
         ms = event_time_ms(torch, lambda: ctx.disparity_dev(d_l, d_r, d_o, win=1, max_disp=0), ks, kw)
         u = W * W * H
