@@ -353,7 +353,7 @@ def main():
         def mstep():
             ctx.match_dev(td1, ts1, td2, ts2, 1000.0, oc, os_, om, od, ot)
 
-        msteps = 3
+        msteps = 10
         mstep()
         torch.cuda.synchronize()
         if world > 1:
