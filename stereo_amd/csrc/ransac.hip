@@ -188,12 +188,14 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_error_kernel(
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // (`sum` is tied into both asm blocks so that the adds between them stay between them)
+// reads the group that starts OFF bytes behind addr
+template <int OFF>
 __device__ __forceinline__ void lds_issue4(unsigned addr, f32x4 &r0, f32x4 &r1, f32x4 &r2, f32x4 &r3, float &sum)
 {
-    asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\t"
-                 "ds_read_b128 %2, %5 offset:32\n\tds_read_b128 %3, %5 offset:48"
+    asm volatile("ds_read_b128 %0, %5 offset:%6\n\tds_read_b128 %1, %5 offset:%7\n\t"
+                 "ds_read_b128 %2, %5 offset:%8\n\tds_read_b128 %3, %5 offset:%9"
                  : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "+v"(sum)
-                 : "v"(addr)
+                 : "v"(addr), "n"(OFF), "n"(OFF + 16), "n"(OFF + 32), "n"(OFF + 48)
                  : "memory");
 }
 // the reads above are complete after this
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(128) void ransac_reduce_kernel(const float *__restr
 {
     // two waves per hypothesis: wave 1 compacts tile t into list[t & 1] while wave 0 runs the
     // chain over tile t - 1 in the other buffer; one barrier per tile
-    __shared__ __align__(16) float list[2][RD_TILE + 32];
+    __shared__ __align__(16) float list[2][RD_TILE + 48];
     __shared__ int fill[2];
     const int h = blockIdx.x, lane = threadIdx.x & 63;
     const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 1;
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(128) void ransac_reduce_kernel(const float *__restr
                 }
                 // whole groups are read; a group past the end is all +0, which leaves the
                 // (non-negative) sum as it is
-                if (lane < 32) dst[m + lane] = 0.0f;
+                if (lane < 48) dst[m + lane] = 0.0f;
                 if (lane == 0) fill[t & 1] = m;
             }
         } else if (t > 0) {
@@ -274,15 +276,19 @@ __global__ __launch_bounds__(128) void ransac_reduce_kernel(const float *__restr
                     (unsigned)(size_t)(__attribute__((address_space(3))) float *)list[(t - 1) & 1];
                 const int groups = (m + 15) >> 4;
                 f32x4 a0, a1, a2, a3, b0, b1, b2, b3;
-                lds_issue4(lbase, a0, a1, a2, a3, sum);
+                // (three groups of zeros follow the list, so the reads one and two groups ahead
+                // need no clamping: immediate offsets from one address that advances per step)
+                unsigned at = lbase;
+                lds_issue4<0>(at, a0, a1, a2, a3, sum);
                 lds_wait(a0, a1, a2, a3, sum);
                 for (int g = 0; g < groups; g += 2) {
-                    lds_issue4(lbase + 64u * (unsigned)min(g + 1, groups), b0, b1, b2, b3, sum);
+                    lds_issue4<64>(at, b0, b1, b2, b3, sum);
                     chain16(sum, a0, a1, a2, a3);
                     lds_wait(b0, b1, b2, b3, sum);
-                    lds_issue4(lbase + 64u * (unsigned)min(g + 2, groups), a0, a1, a2, a3, sum);
+                    lds_issue4<128>(at, a0, a1, a2, a3, sum);
                     chain16(sum, b0, b1, b2, b3);
                     lds_wait(a0, a1, a2, a3, sum);
+                    at += 128u;
                 }
                 count += m;
             }
