@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define STX_VERSION 100 /* 0.1.0 */
+#define STX_VERSION 200 /* 0.2.0 */
 
 #define STX_DESC_LEN 128 /* DESC_LENGTH, stereo/Features.h:46 */
 
@@ -98,6 +98,14 @@ int stx_set_match_algo(stx_ctx *ctx, int algo);
 /* Choose the D1-ext disparity kernel (STX_DISP_*).  Both give identical
  * outputs; this exists for testing and benchmarking. */
 int stx_set_disparity_algo(stx_ctx *ctx, int algo);
+
+/* How the host-pointer entry points move the caller's buffers.  on = 1 (default;
+ * STX_HOST_PIPELINE=0 in the environment turns it off): rows are copied into pinned staging
+ * memory by `threads` host threads including the caller (0: STX_HOST_THREADS, else a default
+ * of at most 8) and a call is cut into `chunks` (0: STX_HOST_CHUNKS, else by size; at most 8)
+ * whose upload, kernel and download overlap on three streams.  on = 0: plain hipMemcpyAsync
+ * of the caller's pageable buffers around one kernel launch.  Results are identical. */
+int stx_set_host_pipeline(stx_ctx *ctx, int on, int threads, int chunks);
 
 /* ---- M: descriptor matching --------------------------------------------
  * Replaces MatchDescriptors (Features.h:195-196).  desc1/desc2 are [n][128]
@@ -310,6 +318,45 @@ int stx_rectify_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const uint8_t *i
                              size_t stride, const float Hinv0[9], const float Hinv1[9], int win,
                              int max_disp, int cost_mode, uint8_t *out, size_t out_stride,
                              uint8_t *rect0, uint8_t *rect1, size_t rect_stride);
+
+/* ---- several GPUs in one process -------------------------------
+ * The reference is one process with one thread (main.cpp:116-388); a drop-in that wants more
+ * than one GPU therefore shards inside the library: one context, stream and host thread per
+ * device, no collective -- every device uploads what it needs from the caller's host buffers
+ * and writes its share of the result straight back.  (The one-process-per-GPU form with an
+ * RCCL gather is stereo_amd/dist.py.)  Results are bit-identical to the single-context calls.
+ * device_ids = NULL: devices 0 .. n_devices-1; n_devices = 0: every visible device. */
+#define STX_MULTI_MAX_DEVICES 16
+typedef struct stx_multi stx_multi;
+int stx_multi_create(stx_multi **out, const int *device_ids, int n_devices);
+void stx_multi_destroy(stx_multi *m);
+int stx_multi_size(const stx_multi *m);
+/* Device k's context (owned by m), e.g. for stx_set_match_algo. */
+stx_ctx *stx_multi_context(stx_multi *m, int k);
+
+/* ComputeDepthImage (Stereography.h:53-55) for a batch of pairs (BASELINE config 4): pair p at
+ * img* + p*pair_stride, map p at out + p*out_pair_stride; pairs are dealt to the devices in
+ * contiguous shares.  Parameters as stx_disparity_u8.  Host pointers. */
+int stx_disparity_batch_u8(stx_multi *m, const uint8_t *img0, const uint8_t *img1, int n_pairs, int w,
+                           int h, size_t stride, size_t pair_stride, int win, int max_disp,
+                           int cost_mode, uint8_t *out, size_t out_stride, size_t out_pair_stride);
+
+/* ComputeDepthImage for ONE large pair (BASELINE config 3), sharded by epipolar row bands
+ * (the search is row-local, Stereography.cpp:664-686): device k computes a contiguous band of
+ * rows and reads the win/2 halo rows above and below it from the caller's images (SURVEY 8e
+ * row 2).  Parameters as stx_disparity_u8 / _u16.  Host pointers. */
+int stx_disparity_rowband_u8(stx_multi *m, const uint8_t *img0, const uint8_t *img1, int w, int h,
+                             size_t stride, int win, int max_disp, int cost_mode, uint8_t *out,
+                             size_t out_stride);
+int stx_disparity_rowband_u16(stx_multi *m, const uint8_t *img0, const uint8_t *img1, int w, int h,
+                              size_t stride, int win, int max_disp, int cost_mode, uint16_t *out,
+                              size_t out_stride);
+
+/* MatchDescriptors (Features.h:195-196) with list1's queries sharded over the devices and list2
+ * replicated.  Parameters and outputs as stx_match.  Host pointers. */
+int stx_match_multi(stx_multi *m, const float *desc1, const float *score1, int n1, const float *desc2,
+                    const float *score2, int n2, float dist_limit, int32_t *closest, int32_t *second,
+                    float *min_dist, float *second_dist, uint8_t *status);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,7 @@ points without the built library raises.
 from ._lib import StereoHipError, load_library, library_path
 from .api import (
     Context,
+    MultiContext,
     Feature,
     MatchDescriptors,
     FindFASTFeatures,
@@ -34,7 +35,7 @@ from .api import (
 from .ransac import FindFundamentalMatrixWithRANSAC
 
 __all__ = [
-    "StereoHipError", "load_library", "library_path", "Context", "Feature",
+    "StereoHipError", "load_library", "library_path", "Context", "MultiContext", "Feature",
     "MatchDescriptors", "FindFASTFeatures", "ScoreAndClusterFeatures", "ClusterFeatures", "CreateSIFTDescriptors", "FindFundamentalMatrixWithRANSAC", "RectifyImage", "ComputeDepthImage",
     "MATCH_FAILED", "MATCH_SCORE", "MATCH_RATIO", "MATCH_ACCEPTED",
     "NN_RATIO", "MAX_DIST_BETWEEN_MATCHES",

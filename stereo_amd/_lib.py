@@ -43,6 +43,19 @@ PROTOTYPES = {
     "stx_synchronize": (C.c_int, [_vp]),
     "stx_set_match_algo": (C.c_int, [_vp, C.c_int]),
     "stx_set_disparity_algo": (C.c_int, [_vp, C.c_int]),
+    "stx_set_host_pipeline": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
+    "stx_multi_create": (C.c_int, [C.POINTER(_vp), C.POINTER(C.c_int), C.c_int]),
+    "stx_multi_destroy": (None, [_vp]),
+    "stx_multi_size": (C.c_int, [_vp]),
+    "stx_multi_context": (_vp, [_vp, C.c_int]),
+    "stx_disparity_batch_u8": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
+                                         C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, C.c_size_t]),
+    "stx_disparity_rowband_u8": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                           C.c_int, _vp, C.c_size_t]),
+    "stx_disparity_rowband_u16": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                            C.c_int, _vp, C.c_size_t]),
+    "stx_match_multi": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_float,
+                                  _vp, _vp, _vp, _vp, _vp]),
     "stx_match": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_float,
                             _vp, _vp, _vp, _vp, _vp]),
     "stx_match_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_float,

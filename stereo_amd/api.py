@@ -94,6 +94,12 @@ class Context:
     def set_disparity_algo(self, algo):
         check(self._lib.stx_set_disparity_algo(self._h, int(algo)), "stx_set_disparity_algo")
 
+    def set_host_pipeline(self, on=True, threads=0, chunks=0):
+        """How host-pointer calls move their buffers: pinned staging + chunked overlap (on), or
+        plain hipMemcpyAsync of the caller's pageable arrays (off).  Same results either way."""
+        check(self._lib.stx_set_host_pipeline(self._h, int(bool(on)), int(threads), int(chunks)),
+              "stx_set_host_pipeline")
+
     # -- M ------------------------------------------------------------------
     def match(self, desc1, score1, desc2, score2, dist_limit=MAX_DIST_BETWEEN_MATCHES):
         """Arrays in, per-query arrays out: (closest, second, min_dist, second_dist, status)."""
@@ -408,6 +414,85 @@ class Context:
             self._h, img0.data_ptr(), img1.data_ptr(), w, h, int(band_row0), int(full_h),
             int(img0.stride(0)), int(row0), int(rows), int(win), int(max_disp), int(cost_mode),
             out.data_ptr(), int(out.stride(0)) * ob, ob), "stx_disparity_rowband_dev")
+
+
+class MultiContext:
+    """stx_multi: several GPUs behind one handle in ONE process (the C++ drop-in's way to more
+    than one GPU; one context, stream and host thread per device, no collective)."""
+
+    def __init__(self, device_ids=None):
+        self._lib = _lib.load_library()
+        h = C.c_void_p()
+        if device_ids is None:
+            check(self._lib.stx_multi_create(C.byref(h), None, 0), "stx_multi_create")
+        else:
+            ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+            check(self._lib.stx_multi_create(C.byref(h), ids, len(device_ids)), "stx_multi_create")
+        self._h = h
+        self.size = int(self._lib.stx_multi_size(h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.stx_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover - interpreter shutdown order
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_match_algo(self, algo):
+        for k in range(self.size):
+            check(self._lib.stx_set_match_algo(self._lib.stx_multi_context(self._h, k), int(algo)),
+                  "stx_set_match_algo")
+
+    def disparity_batch(self, img0, img1, win=1, max_disp=0, cost_mode=COST_SAD):
+        """img0/img1: [n,H,W] uint8 arrays (a batch of pairs, dealt to the devices in contiguous
+        shares).  Returns the [n,H,W] uint8 maps."""
+        a, b = np.ascontiguousarray(img0, np.uint8), np.ascontiguousarray(img1, np.uint8)
+        if a.ndim != 3 or a.shape != b.shape:
+            raise ValueError("img0 and img1 must be [n,H,W] arrays of one shape")
+        n, h, w = a.shape
+        out = np.zeros((n, h, w), np.uint8)
+        check(self._lib.stx_disparity_batch_u8(self._h, _ptr(a), _ptr(b), n, w, h, max(w, 1), max(w, 1) * h,
+                                               int(win), int(max_disp), int(cost_mode), _ptr(out), max(w, 1),
+                                               max(w, 1) * h), "stx_disparity_batch_u8")
+        return out
+
+    def disparity_rowbands(self, img0, img1, win=1, max_disp=0, cost_mode=COST_SAD, out_dtype=np.uint8):
+        """One pair, sharded over the devices by row bands with win//2 halo rows."""
+        _check_image(img0, "img0")
+        _check_image(img1, "img1")
+        if img0.shape != img1.shape:
+            raise ValueError("img0 and img1 must have the same shape")
+        a, b = np.ascontiguousarray(img0), np.ascontiguousarray(img1)
+        h, w = a.shape
+        out_dtype = np.dtype(out_dtype)
+        out = np.zeros((h, w), out_dtype)
+        fn = {1: self._lib.stx_disparity_rowband_u8, 2: self._lib.stx_disparity_rowband_u16}[out_dtype.itemsize]
+        check(fn(self._h, _ptr(a), _ptr(b), w, h, max(w, 1), int(win), int(max_disp), int(cost_mode), _ptr(out),
+                 max(w, 1) * out_dtype.itemsize), "stx_disparity_rowband")
+        return out
+
+    def match(self, desc1, score1, desc2, score2, dist_limit=MAX_DIST_BETWEEN_MATCHES):
+        """As Context.match, list1's queries sharded over the devices."""
+        desc1 = np.ascontiguousarray(desc1, np.float32).reshape(-1, DESC_LENGTH)
+        desc2 = np.ascontiguousarray(desc2, np.float32).reshape(-1, DESC_LENGTH)
+        score1 = np.ascontiguousarray(score1, np.float32).reshape(-1)
+        score2 = np.ascontiguousarray(score2, np.float32).reshape(-1)
+        n1, n2 = desc1.shape[0], desc2.shape[0]
+        if score1.shape[0] != n1 or score2.shape[0] != n2:
+            raise ValueError("score arrays must have one entry per descriptor")
+        closest = np.full(n1, -1, np.int32)
+        second = np.full(n1, -1, np.int32)
+        min_dist = np.full(n1, -1.0, np.float32)
+        second_dist = np.full(n1, -1.0, np.float32)
+        status = np.zeros(n1, np.uint8)
+        check(self._lib.stx_match_multi(self._h, _ptr(desc1), _ptr(score1), n1, _ptr(desc2), _ptr(score2), n2,
+                                        C.c_float(dist_limit), _ptr(closest), _ptr(second), _ptr(min_dist),
+                                        _ptr(second_dist), _ptr(status)), "stx_match_multi")
+        return closest, second, min_dist, second_dist, status
 
 
 def _check_image(a, name, writable=False):

@@ -233,7 +233,6 @@ template <int RING> __device__ __forceinline__ int band_slot(int yy) { return (y
 constexpr int BAND_ND = 16;          // disparities per wave
 constexpr int BAND_COLS = 256;       // columns per tile (64 lanes x 4)
 constexpr unsigned BAND_SH = 12;     // key = cost << 12 | (4095 - d)
-constexpr unsigned BAND_LOW = (1u << BAND_SH) - 1;
 // Valid keys stay below 2^28 (cost <= 255*81 < 2^15, shifted by 12).  An invalid candidate
 // (img1 centre 0 or left of the image) adds BAND_MASKED, a disparity past D adds
 // BAND_PAST_D; the two can add up without wrapping, and "no candidate yet" (BAND_INIT)
@@ -730,7 +729,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
 }
 
 template <int R, bool SSD>
-int launch_band(stx_ctx *ctx, BandArgs a, int n_pairs)
+int launch_band(stx_ctx *ctx, BandArgs a, int n_pairs, void *keys, size_t keys_bytes)
 {
     constexpr int HL = (R + 3) / 4;
     constexpr int TILE_OUT = BAND_COLS - 8 * HL;
@@ -754,9 +753,15 @@ int launch_band(stx_ctx *ctx, BandArgs a, int n_pairs)
     const int bands = (a.rows + a.bh - 1) / a.bh;
     if (bands > 65535 || n_pairs > 65535) return STX_ERR_TOO_LARGE;
     if (npass > 1) {
-        int err;
-        a.keys = (unsigned *)stx_workspace(ctx, STX_SLOT_DISP_KEYS, sizeof(unsigned) * (size_t)n_pairs * a.rows * a.w, &err);
-        if (!a.keys) return err;
+        const size_t need = sizeof(unsigned) * (size_t)n_pairs * a.rows * a.w;
+        if (keys) {  // caller-provided scratch (the no-allocation entry point)
+            if (need > keys_bytes) return STX_ERR_TOO_LARGE;
+            a.keys = static_cast<unsigned *>(keys);
+        } else {
+            int err;
+            a.keys = (unsigned *)stx_workspace(ctx, STX_SLOT_DISP_KEYS, need, &err);
+            if (!a.keys) return err;
+        }
     } else {
         a.keys = nullptr;
     }
@@ -769,12 +774,11 @@ int launch_band(stx_ctx *ctx, BandArgs a, int n_pairs)
         a.last_pass = p == npass - 1;
         const int rw = BAND_COLS + BAND_ND * nw;
         const size_t lds = sizeof(unsigned) * ((size_t)band_ring(2 * R + 1) * (BAND_COLS + 2 * rw) + 2 * BAND_COLS);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(disp_band_kernel<R, SSD>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+        const int rc = stx_set_lds_attr(ctx, reinterpret_cast<const void *>(disp_band_kernel<R, SSD>), (int)lds);
+        if (rc != STX_OK) return rc;
         hipLaunchKernelGGL((disp_band_kernel<R, SSD>), dim3(xt, bands, n_pairs), dim3(64 * nw), lds,
                            ctx->stream, a);
-        e = hipGetLastError();
+        const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
     return STX_OK;
@@ -786,7 +790,7 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
                          int n_pairs, int w, int h, size_t stride, size_t pair_stride,
                          int row0, int rows, int win, int max_disp, int cost_mode,
                          void *d_out, size_t out_stride, size_t out_pair_stride,
-                         int out_bytes)
+                         int out_bytes, void *keys, size_t keys_bytes)
 {
     if (w <= 0 || h <= 0 || rows <= 0 || n_pairs <= 0) return STX_OK;
     if (rows > 65535 * EXT_TY || n_pairs > 65535) return STX_ERR_TOO_LARGE;
@@ -816,22 +820,22 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
         a.out_stride = out_stride; a.out_pair_stride = out_pair_stride; a.out_bytes = out_bytes;
         if (ssd) {
             switch (r) {
-            case 1: return launch_band<1, true>(ctx, a, n_pairs);
-            case 2: return launch_band<2, true>(ctx, a, n_pairs);
-            case 3: return launch_band<3, true>(ctx, a, n_pairs);
-            case 4: return launch_band<4, true>(ctx, a, n_pairs);
-            default: return launch_band<5, true>(ctx, a, n_pairs);
+            case 1: return launch_band<1, true>(ctx, a, n_pairs, keys, keys_bytes);
+            case 2: return launch_band<2, true>(ctx, a, n_pairs, keys, keys_bytes);
+            case 3: return launch_band<3, true>(ctx, a, n_pairs, keys, keys_bytes);
+            case 4: return launch_band<4, true>(ctx, a, n_pairs, keys, keys_bytes);
+            default: return launch_band<5, true>(ctx, a, n_pairs, keys, keys_bytes);
             }
         }
         switch (r) {
-        case 0: return launch_band<0, false>(ctx, a, n_pairs);
-        case 1: return launch_band<1, false>(ctx, a, n_pairs);
-        case 2: return launch_band<2, false>(ctx, a, n_pairs);
-        case 3: return launch_band<3, false>(ctx, a, n_pairs);
-        case 4: return launch_band<4, false>(ctx, a, n_pairs);
-        case 5: return launch_band<5, false>(ctx, a, n_pairs);
-        case 6: return launch_band<6, false>(ctx, a, n_pairs);
-        default: return launch_band<7, false>(ctx, a, n_pairs);
+        case 0: return launch_band<0, false>(ctx, a, n_pairs, keys, keys_bytes);
+        case 1: return launch_band<1, false>(ctx, a, n_pairs, keys, keys_bytes);
+        case 2: return launch_band<2, false>(ctx, a, n_pairs, keys, keys_bytes);
+        case 3: return launch_band<3, false>(ctx, a, n_pairs, keys, keys_bytes);
+        case 4: return launch_band<4, false>(ctx, a, n_pairs, keys, keys_bytes);
+        case 5: return launch_band<5, false>(ctx, a, n_pairs, keys, keys_bytes);
+        case 6: return launch_band<6, false>(ctx, a, n_pairs, keys, keys_bytes);
+        default: return launch_band<7, false>(ctx, a, n_pairs, keys, keys_bytes);
         }
     }
     const size_t lds = (size_t)(EXT_TX + 2 * r) * (EXT_TY + 2 * r) +

@@ -818,7 +818,13 @@ __global__ __launch_bounds__(X1_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
     int tiles_total, long long per, long long flat_total, int nsub, int subcap,
     int *__restrict__ cand_count, int *__restrict__ cand)
 {
-    __shared__ uint4 tile[2][MF_TILE_U4];  // 2 x 33 KiB
+    // Two separate LDS objects, not one [2][..] array: the tile staging is an LDS DMA
+    // (global_load_lds) tracked by vmcnt, and the compiler only lets a ds_read pass an
+    // outstanding DMA when it can prove that the read's object is not the DMA's target.  With
+    // one array every fragment read of the other buffer waited for the staging just issued
+    // (s_waitcnt vmcnt(0) right behind stage(tt + 2)), i.e. the double buffering hid nothing.
+    __shared__ uint4 tile0[MF_TILE_U4];  // 33 KiB
+    __shared__ uint4 tile1[MF_TILE_U4];  // 33 KiB
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -827,20 +833,32 @@ __global__ __launch_bounds__(X1_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
     const int col = lane & 31;
     const float nbmax = *bmax;
 
-    auto stage = [&](int t, int buf) {
+    // The per-lane part of every staging address is rebuilt from the lane number on each call
+    // (the empty asm hides that it is loop invariant): held across the loop, these addresses
+    // were spilled, and a scratch reload is a vector memory load that completes in order BEHIND
+    // the staging loads -- its s_waitcnt vmcnt(0) waited for the tile just requested.
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    auto stage = [&](int t, uint4 *dst) __attribute__((always_inline)) {
         const uint4 *src = frag16 + (size_t)t * MF_TILE_U4;
+        int l;  // lane number, from the hardware: nothing to keep live (or spill) across the loop
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
 #pragma unroll
         for (int k = 0; k < 32 / X1_WAVES; ++k) {
-            const int chunk = (k * X1_WAVES + wave) * 64;  // uint4 units, 1 KiB per wave-instruction
+            const int chunk = (k * X1_WAVES + wave_s) * 64;  // uint4 units, 1 KiB per wave-instruction
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(src + chunk + lane),
-                (__attribute__((address_space(3))) void *)(&tile[buf][chunk]), 16, 0, 0);
+                (const __attribute__((address_space(1))) void *)(src + chunk + l),
+                (__attribute__((address_space(3))) void *)(&dst[chunk]), 16, 0, 0);
         }
-        if (wave == 0)  // the tile's seeds
+        if (wave_s == 0)  // the tile's seeds
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(src + MF_TJ1 * 512 + lane),
-                (__attribute__((address_space(3))) void *)(&tile[buf][MF_TJ1 * 512]), 16, 0, 0);
+                (const __attribute__((address_space(1))) void *)(src + MF_TJ1 * 512 + l),
+                (__attribute__((address_space(3))) void *)(&dst[MF_TJ1 * 512]), 16, 0, 0);
     };
+    // A wave's own staging loads have landed (what the barrier behind it then extends to the
+    // whole workgroup).  Explicit: correctness must not rest on waits the compiler happens to add.
+    // (the builtin, not inline asm: the compiler's own wait-count bookkeeping sees it and stops
+    // treating the staged tile as pending; 0x0F70 = vmcnt(0), expcnt and lgkmcnt untouched)
+    auto staged = [&]() __attribute__((always_inline)) { __builtin_amdgcn_s_waitcnt(0x0F70); };
 
     long long flat = (long long)blockIdx.x * per;
     const long long flat_end = flat + per < flat_total ? flat + per : flat_total;
@@ -901,39 +919,45 @@ __global__ __launch_bounds__(X1_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
         // registers, so the buffer can be refilled (tile + 2) and the next tile's first block
         // read.  (After the last tile's barrier nobody reads LDS any more, so the next piece
         // may stage at once.)
-        stage(t_begin, 0);
+        stage(t_begin, tile0);
+        staged();
         __syncthreads();
-        if (ntiles > 1) stage(t_begin + 1, 1);
+        if (ntiles > 1) stage(t_begin + 1, tile1);
         uint4 fA[8], fB[8];
         f32x16 x0, x1, y0, y1;  // two accumulator pairs: one computes while the other is closed
-        load_frag(tile[0] + lane, fA);
-        f32x16 c = load_seeds(tile[0], 0, half);
+        load_frag(tile0 + lane, fA);
+        f32x16 c = load_seeds(tile0, 0, half);
 #define X1_BLOCK(FIRST, F, X0, X1, P0, P1, SEEDS, KB, JPREV)                                         \
     x1_block<FIRST>(F, qh0, qh1, X0, X1, P0, P1, c, SEEDS, KB, b0, b1, live0, live1, JPREV, half, n2, \
                     list0, list1, subcap)
-#pragma unroll 1
-        for (int tt = 0; tt < ntiles; ++tt) {
-            const int buf = tt & 1;
-            const uint4 *bf = tile[buf] + lane;
+        // one tile: `cur` is the buffer being consumed, `oth` the one tile tt + 1 lands in
+        auto tile_step = [&](int tt, uint4 *cur, uint4 *oth) __attribute__((always_inline)) {
+            const uint4 *bf = cur + lane;
             const int j0 = (t_begin + tt) * MF_TILE_ROWS1;
             load_frag(bf + 512, fB);
             __builtin_amdgcn_sched_barrier(0);
             if (tt == 0)
-                X1_BLOCK(true, fA, x0, x1, y0, y1, tile[buf], 1, 0);
+                X1_BLOCK(true, fA, x0, x1, y0, y1, cur, 1, 0);
             else
-                X1_BLOCK(false, fA, x0, x1, y0, y1, tile[buf], 1, j0 - MF_JB);
+                X1_BLOCK(false, fA, x0, x1, y0, y1, cur, 1, j0 - MF_JB);
             load_frag(bf + 1024, fA);
             __builtin_amdgcn_sched_barrier(0);
-            X1_BLOCK(false, fB, y0, y1, x0, x1, tile[buf], 2, j0);
+            X1_BLOCK(false, fB, y0, y1, x0, x1, cur, 2, j0);
             load_frag(bf + 1536, fB);
             __builtin_amdgcn_sched_barrier(0);
-            X1_BLOCK(false, fA, x0, x1, y0, y1, tile[buf], 3, j0 + MF_JB);
+            X1_BLOCK(false, fA, x0, x1, y0, y1, cur, 3, j0 + MF_JB);
+            staged();         // this wave's share of tile tt + 1, issued one tile ago
             __syncthreads();  // tile tt + 1 has landed; nobody reads tile tt from LDS any more
-            if (tt + 2 < ntiles) stage(t_begin + tt + 2, buf);
-            if (tt + 1 < ntiles) load_frag(tile[buf ^ 1] + lane, fA);
+            if (tt + 2 < ntiles) stage(t_begin + tt + 2, cur);
+            if (tt + 1 < ntiles) load_frag(oth + lane, fA);
             __builtin_amdgcn_sched_barrier(0);
             // (after the piece's last tile the other buffer holds stale seeds: read, never used)
-            X1_BLOCK(false, fB, y0, y1, x0, x1, tile[buf ^ 1], 0, j0 + 2 * MF_JB);
+            X1_BLOCK(false, fB, y0, y1, x0, x1, oth, 0, j0 + 2 * MF_JB);
+        };
+#pragma unroll 1
+        for (int tt = 0; tt < ntiles; tt += 2) {
+            tile_step(tt, tile0, tile1);
+            if (tt + 1 < ntiles) tile_step(tt + 1, tile1, tile0);
         }
 #undef X1_BLOCK
         {   // drain: the last block (in y0, y1)

@@ -20,7 +20,8 @@
 #include "stx_internal.h"
 
 #include <math.h>
-#include <vector>
+#include <memory>
+#include <new>
 
 namespace {
 
@@ -329,10 +330,12 @@ int stx_launch_ransac_score(stx_ctx *ctx, const float *hyp, int n_hyp, const flo
     rc = stx_invert_homography(K2, cams.k2inv);  // :168
     if (rc) return rc;
     for (int k = 0; k < 9; ++k) cams.k2[k] = K2[k];
-    std::vector<float> rec((size_t)RS_REC * n_hyp, 0.0f);
+    // no exception may cross the C boundary: nothrow allocation, value-initialised
+    std::unique_ptr<float[]> rec(new (std::nothrow) float[(size_t)RS_REC * n_hyp]());
+    if (!rec) return STX_ERR_HOST_OOM;
     for (int hh = 0; hh < n_hyp; ++hh) {
         const float *src = hyp + (size_t)hh * STX_HYP_FLOATS;
-        float *dst = rec.data() + (size_t)hh * RS_REC;
+        float *dst = rec.get() + (size_t)hh * RS_REC;
         for (int k = 0; k < 9; ++k) dst[k] = src[k];
         rc = stx_invert_homography(src + 9, dst + 9);  // R.inverse(), :175
         if (rc) return rc;
@@ -342,7 +345,7 @@ int stx_launch_ransac_score(stx_ctx *ctx, const float *hyp, int n_hyp, const flo
         int32_t *ex = reinterpret_cast<int32_t *>(dst + 34);
         for (int k = 0; k < 8; ++k) ex[k] = exclude ? exclude[(size_t)hh * 8 + k] : -1;
     }
-    STX_HIP(hipMemcpyAsync(d_rec, rec.data(), rec_bytes, hipMemcpyHostToDevice, ctx->stream));
+    STX_HIP(hipMemcpyAsync(d_rec, rec.get(), rec_bytes, hipMemcpyHostToDevice, ctx->stream));
     // the records were staged from pageable memory; wait so `rec` may go out of scope
     STX_HIP(hipStreamSynchronize(ctx->stream));
     if (n > 0) {

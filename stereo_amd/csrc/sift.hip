@@ -25,7 +25,8 @@
 #include "stx_internal.h"
 
 #include <math.h>
-#include <vector>
+#include <memory>
+#include <new>
 
 namespace {
 
@@ -163,18 +164,24 @@ static int sift_tables(stx_ctx *ctx, const float **d_tables)
     float *d = (float *)stx_workspace(ctx, STX_SLOT_SIFT_TABLES, sizeof(float) * count, &err);
     if (!d) return err;
     if (!built) {
-        std::vector<float> host(count);
+        // no exception may cross the C boundary: nothrow allocation
+        std::unique_ptr<float[]> host(new (std::nothrow) float[count]);
+        if (!host) return STX_ERR_HOST_OOM;
         for (int vy = 0; vy < 256; ++vy)
             for (int vx = 0; vx < 256; ++vx) {
                 const float gX = (float)vx, gY = (float)vy;
                 // :974-978; atan of a float argument is the float overload in the reference's C++
                 host[(size_t)vy * 256 + vx] = vx != 0 ? atanf(gY / gX) * 180.f / SIFT_PI : 90.f;
             }
-        int rc = stx_gaussian_kernel(9, 1.f, host.data() + 65536);
-        if (rc) return rc;
-        rc = stx_gaussian_kernel(4, 1.f, host.data() + 65536 + 81);
-        if (rc) return rc;
-        STX_HIP(hipMemcpy(d, host.data(), sizeof(float) * count, hipMemcpyHostToDevice));
+        int rc = stx_gaussian_kernel(9, 1.f, host.get() + 65536);
+        if (!rc) rc = stx_gaussian_kernel(4, 1.f, host.get() + 65536 + 81);
+        if (!rc) rc = (int)hipMemcpy(d, host.get(), sizeof(float) * count, hipMemcpyHostToDevice);
+        if (rc) {  // a failed build must not be taken for a finished one by the next call
+            ctx->slot_bytes[STX_SLOT_SIFT_TABLES] = 0;
+            (void)hipFree(d);
+            ctx->slot_ptr[STX_SLOT_SIFT_TABLES] = nullptr;
+            return rc;
+        }
     }
     *d_tables = d;
     return STX_OK;

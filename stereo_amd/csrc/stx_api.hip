@@ -1,6 +1,7 @@
 // C-ABI entry points of libstereo_hip.so: context management and the host-pointer
 // forms, which stage through context-owned device buffers and call the kernel
 // launchers in disparity.hip / rectify.hip / match.hip.
+#include <mutex>
 #include <new>
 #include <string.h>
 
@@ -39,13 +40,15 @@ extern "C" int stx_create(stx_ctx **out, int device)
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) return (int)e;
     if (device < 0 || device >= n) return STX_ERR_NO_DEVICE;
-    STX_HIP(hipSetDevice(device));
+    stx_device_guard guard(device);
+    if (guard.err) return guard.err;
     stx_ctx *ctx = new (std::nothrow) stx_ctx();
     if (!ctx) return STX_ERR_HOST_OOM;
     memset(ctx, 0, sizeof(*ctx));
     ctx->device = device;
     ctx->stream = nullptr;
     ctx->match_algo = STX_MATCH_AUTO;
+    ctx->host_pipeline = -1;  // STX_HOST_PIPELINE, default on
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) {
@@ -60,8 +63,9 @@ extern "C" int stx_create(stx_ctx **out, int device)
 extern "C" void stx_destroy(stx_ctx *ctx)
 {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    stx_device_guard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    stx_host_release(ctx);
     for (int i = 0; i < STX_SLOT_COUNT; ++i)
         if (ctx->slot_ptr[i]) (void)hipFree(ctx->slot_ptr[i]);
     delete ctx;
@@ -77,7 +81,7 @@ extern "C" int stx_set_stream(stx_ctx *ctx, void *hip_stream)
 extern "C" int stx_synchronize(stx_ctx *ctx)
 {
     if (!ctx) return STX_ERR_INVALID_ARG;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     STX_HIP(hipStreamSynchronize(ctx->stream));
     return STX_OK;
 }
@@ -100,12 +104,29 @@ extern "C" int stx_set_disparity_algo(stx_ctx *ctx, int algo)
     return STX_OK;
 }
 
+extern "C" int stx_set_host_pipeline(stx_ctx *ctx, int on, int threads, int chunks)
+{
+    if (!ctx || threads < 0 || chunks < 0 || chunks > STX_HOST_MAX_CHUNKS) return STX_ERR_INVALID_ARG;
+    ctx->host_pipeline = on ? 1 : 0;
+    if (threads != ctx->host_threads) {
+        // the workers are started lazily with the new count
+        stx_device_guard guard(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        stx_host_release(ctx);
+    }
+    ctx->host_threads = threads;
+    ctx->host_chunks = chunks;
+    return STX_OK;
+}
+
 void *stx_workspace(stx_ctx *ctx, int slot, size_t bytes, int *err)
 {
     *err = STX_OK;
     if (bytes == 0) bytes = 256;
     if (ctx->slot_bytes[slot] >= bytes) return ctx->slot_ptr[slot];
-    hipError_t e = hipStreamSynchronize(ctx->stream);
+    // not just ctx->stream: the caller may have switched streams (stx_set_stream) with work
+    // that uses the old buffer still in flight on the previous one
+    hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) { *err = (int)e; return nullptr; }
     if (ctx->slot_ptr[slot]) {
         (void)hipFree(ctx->slot_ptr[slot]);
@@ -121,6 +142,27 @@ void *stx_workspace(stx_ctx *ctx, int slot, size_t bytes, int *err)
     return p;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel) and only ever
+// upwards: the attribute belongs to the device's copy of the function, not to a context, so
+// the record is process-wide.
+int stx_set_lds_attr(stx_ctx *ctx, const void *fn, int lds)
+{
+    struct Entry { int device; const void *fn; int lds; };
+    static Entry table[256];
+    static int count = 0;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    int slot = -1;
+    for (int i = 0; i < count; ++i)
+        if (table[i].device == ctx->device && table[i].fn == fn) { slot = i; break; }
+    if (slot >= 0 && table[slot].lds >= lds) return STX_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    if (slot < 0 && count < 256) slot = count++;
+    if (slot >= 0) table[slot] = Entry{ctx->device, fn, lds};
+    return STX_OK;
+}
+
 // ---------------------------------------------------------------- M (host) --
 
 extern "C" int stx_match_dev(stx_ctx *ctx, const float *d_desc1, const float *d_score1,
@@ -131,7 +173,7 @@ extern "C" int stx_match_dev(stx_ctx *ctx, const float *d_desc1, const float *d_
     if (!ctx || n1 < 0 || n2 < 0) return STX_ERR_INVALID_ARG;
     if (n1 > 0 && (!d_desc1 || !d_score1)) return STX_ERR_INVALID_ARG;
     if (n2 > 0 && (!d_desc2 || !d_score2)) return STX_ERR_INVALID_ARG;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     if (n1 == 0) return STX_OK;
     return stx_launch_match(ctx, d_desc1, d_score1, n1, d_desc2, d_score2, n2, dist_limit,
                             d_closest, d_second, d_min_dist, d_second_dist, d_status);
@@ -145,7 +187,7 @@ extern "C" int stx_match(stx_ctx *ctx, const float *desc1, const float *score1, 
     if (!ctx || n1 < 0 || n2 < 0) return STX_ERR_INVALID_ARG;
     if (n1 > 0 && (!desc1 || !score1)) return STX_ERR_INVALID_ARG;
     if (n2 > 0 && (!desc2 || !score2)) return STX_ERR_INVALID_ARG;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     if (n1 == 0) return STX_OK;
     int err;
     const size_t d1b = (size_t)n1 * STX_DESC_LEN * sizeof(float);
@@ -167,10 +209,19 @@ extern "C" int stx_match(stx_ctx *ctx, const float *desc1, const float *score1, 
     float *dsd = dmd + n1a;
     uint8_t *dst = (uint8_t *)(dsd + n1a);
     hipStream_t s = ctx->stream;
-    STX_HIP(hipMemcpyAsync(dd1, desc1, d1b, hipMemcpyHostToDevice, s));
-    if (n2 > 0) STX_HIP(hipMemcpyAsync(dd2, desc2, d2b, hipMemcpyHostToDevice, s));
-    STX_HIP(hipMemcpyAsync(ds1, score1, 4 * (size_t)n1, hipMemcpyHostToDevice, s));
-    if (n2 > 0) STX_HIP(hipMemcpyAsync(ds2, score2, 4 * (size_t)n2, hipMemcpyHostToDevice, s));
+    // the two descriptor lists (config 5: 102 MB each) go through the staging pipeline
+    const size_t s1b = 4 * (size_t)n1, s2b = 4 * (size_t)n2;
+    if (stx_host_pipeline_on(ctx)) {
+        int prc = stx_host_prepare(ctx, d1b + d2b + s1b + s2b, 0);
+        if (prc) return prc;
+        prc = stx_host_fence(ctx);
+        if (prc) return prc;
+    }
+    int urc = stx_host_upload_flat(ctx, dd1, desc1, d1b, 0);
+    if (!urc) urc = stx_host_upload_flat(ctx, dd2, desc2, d2b, d1b);
+    if (!urc) urc = stx_host_upload_flat(ctx, ds1, score1, s1b, d1b + d2b);
+    if (!urc) urc = stx_host_upload_flat(ctx, ds2, score2, s2b, d1b + d2b + s1b);
+    if (urc) return urc;
     int rc = stx_launch_match(ctx, dd1, ds1, n1, dd2, ds2, n2, dist_limit, dcl, dse, dmd, dsd, dst);
     if (rc != STX_OK) return rc;
     if (closest) STX_HIP(hipMemcpyAsync(closest, dcl, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
@@ -247,7 +298,7 @@ extern "C" int stx_rectify_u8_dev(stx_ctx *ctx, const uint8_t *d_src, int src_w,
     if (rc) return rc;
     rc = check_image(d_dst, dst_w, dst_h, dst_stride);
     if (rc) return rc;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     if (n_images == 0 || dst_w == 0 || dst_h == 0) return STX_OK;
     int err;
     float *d_hinv = (float *)stx_workspace(ctx, STX_SLOT_HINV, sizeof(float) * 9 * (size_t)n_images, &err);
@@ -271,7 +322,7 @@ extern "C" int stx_rectify_rowband_u8_dev(stx_ctx *ctx, const uint8_t *d_src, in
     rc = check_image(d_dst, dst_w, dst_rows, dst_stride);
     if (rc) return rc;
     if ((long long)dst_row0 + dst_rows > (1ll << 24)) return STX_ERR_TOO_LARGE;  // (float)y exact
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     if (dst_w == 0 || dst_rows == 0) return STX_OK;
     int err;
     float *d_hinv = (float *)stx_workspace(ctx, STX_SLOT_HINV, sizeof(float) * 9, &err);
@@ -291,25 +342,9 @@ extern "C" int stx_rectify_u8(stx_ctx *ctx, const uint8_t *src, int src_w, int s
     if (rc) return rc;
     rc = check_image(dst, dst_w, dst_h, dst_stride);
     if (rc) return rc;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     if (dst_w == 0 || dst_h == 0) return STX_OK;
-    int err;
-    hipStream_t s = ctx->stream;
-    // dense device images (pitch == width): see copy_image_h2d
-    const size_t sp = (size_t)(src_w > 0 ? src_w : 1), dp = (size_t)dst_w;
-    uint8_t *dsrc = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG0, sp * (size_t)(src_h > 0 ? src_h : 1), &err);
-    if (!dsrc) return err;
-    uint8_t *ddst = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG1, dp * (size_t)dst_h, &err);
-    if (!ddst) return err;
-    if (src_w > 0 && src_h > 0)
-        STX_HIP(copy_image_h2d(dsrc, sp, src, src_stride, (size_t)src_w, (size_t)src_h, s));
-    if (flags == STX_RECT_PRESERVE_DST)
-        STX_HIP(copy_image_h2d(ddst, dp, dst, dst_stride, (size_t)dst_w, (size_t)dst_h, s));
-    rc = stx_rectify_u8_dev(ctx, dsrc, src_w, src_h, sp, 0, ddst, dst_w, dst_h, dp, 0, Hinv, 1, flags);
-    if (rc) return rc;
-    STX_HIP(copy_image_d2h(dst, dst_stride, ddst, dp, (size_t)dst_w, (size_t)dst_h, s));
-    STX_HIP(hipStreamSynchronize(s));
-    return STX_OK;
+    return stx_rectify_host(ctx, src, src_w, src_h, src_stride, dst, dst_w, dst_h, dst_stride, Hinv, flags);
 }
 
 // ---------------------------------------------------------------- D (host) --
@@ -347,7 +382,7 @@ extern "C" int stx_disparity_rowband_dev(stx_ctx *ctx, const uint8_t *d_img0,
     if (rows > 0 && (band_row0 > need_lo || band_row0 + h < need_hi)) return STX_ERR_INVALID_ARG;
     if (w == 0 || rows == 0) return STX_OK;
     if (!d_img0 || !d_img1 || !d_out) return STX_ERR_INVALID_ARG;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     // A band whose first/last rows are interior rows of the full image has its
     // window clipped only where the halo is present, so clipping against the
     // band equals clipping against the full image.
@@ -367,7 +402,7 @@ extern "C" int stx_disparity_dev(stx_ctx *ctx, const uint8_t *d_img0, const uint
     if (!d_img0 || !d_img1 || !d_out) return STX_ERR_INVALID_ARG;
     if (n_pairs > 1 && (pair_stride < stride * (size_t)h || out_pair_stride < out_stride * (size_t)h))
         return STX_ERR_INVALID_ARG;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     return stx_launch_disparity(ctx, d_img0, d_img1, n_pairs, w, h, stride, pair_stride, 0, h, win,
                                 max_disp, cost_mode, d_out, out_stride, out_pair_stride, out_bytes);
 }
@@ -381,25 +416,9 @@ static int disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1
     if (rc) return rc;
     if (w == 0 || h == 0) return STX_OK;
     if (!img0 || !img1 || !out) return STX_ERR_INVALID_ARG;
-    STX_HIP(hipSetDevice(ctx->device));
-    int err;
-    hipStream_t s = ctx->stream;
-    const size_t p = (size_t)w;  // dense device images: see copy_image_h2d
-    const size_t op = p * (size_t)out_bytes;
-    uint8_t *d0 = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG0, p * (size_t)h, &err);
-    if (!d0) return err;
-    uint8_t *d1 = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG1, p * (size_t)h, &err);
-    if (!d1) return err;
-    uint8_t *dout = (uint8_t *)stx_workspace(ctx, STX_SLOT_OUT, op * (size_t)h, &err);
-    if (!dout) return err;
-    STX_HIP(copy_image_h2d(d0, p, img0, stride, (size_t)w, (size_t)h, s));
-    STX_HIP(copy_image_h2d(d1, p, img1, stride, (size_t)w, (size_t)h, s));
-    rc = stx_launch_disparity(ctx, d0, d1, 1, w, h, p, 0, 0, h, win, max_disp, cost_mode, dout, op, 0,
+    STX_ENTER(ctx);
+    return stx_disparity_host(ctx, img0, img1, 1, w, h, stride, 0, 0, h, win, max_disp, cost_mode, out, out_stride, 0,
                               out_bytes);
-    if (rc) return rc;
-    STX_HIP(copy_image_d2h(out, out_stride, dout, op, (size_t)w * (size_t)out_bytes, (size_t)h, s));
-    STX_HIP(hipStreamSynchronize(s));
-    return STX_OK;
 }
 
 extern "C" int stx_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int w,
@@ -430,7 +449,7 @@ extern "C" int stx_rectify_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const
     if ((rect0 || rect1) && rect_stride < (size_t)w) return STX_ERR_INVALID_ARG;
     if (w == 0 || h == 0) return STX_OK;
     if (!img0 || !img1 || !out) return STX_ERR_INVALID_ARG;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     int err;
     hipStream_t s = ctx->stream;
     const size_t p = (size_t)w;
@@ -442,17 +461,64 @@ extern "C" int stx_rectify_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const
     if (!drect) return err;
     uint8_t *dout = (uint8_t *)stx_workspace(ctx, STX_SLOT_OUT, img, &err);
     if (!dout) return err;
-    STX_HIP(copy_image_h2d(dsrc, p, img0, stride, (size_t)w, (size_t)h, s));
-    STX_HIP(copy_image_h2d(dsrc + img, p, img1, stride, (size_t)w, (size_t)h, s));
+    const bool pipe = stx_host_pipeline_on(ctx);
+    const int nout = 1 + (rect0 ? 1 : 0) + (rect1 ? 1 : 0);
+    if (pipe) {
+        rc = stx_host_prepare(ctx, 2 * img, (size_t)nout * img);
+        if (rc) return rc;
+        rc = stx_host_fence(ctx);
+        if (rc) return rc;
+        uint8_t *pin_in = (uint8_t *)ctx->pin_ptr[0];
+        // row chunks: the staging copy of chunk c+1 runs while chunk c is on the bus
+        const int nc = stx_host_chunks(ctx, img, (size_t)h);
+        for (int k = 0; k < 2; ++k)
+            for (int c = 0; c < nc; ++c) {
+                const size_t r0 = (size_t)h * c / nc, r1 = (size_t)h * (c + 1) / nc;
+                rc = stx_host_upload(ctx, dsrc + k * img + r0 * p, pin_in + k * img + r0 * p,
+                                     (k ? img1 : img0) + r0 * stride, stride, p, r1 - r0, nullptr);
+                if (rc) return rc;
+            }
+        STX_HIP(hipEventRecord(ctx->ev_in[0], ctx->s_in));
+        STX_HIP(hipStreamWaitEvent(s, ctx->ev_in[0], 0));
+    } else {
+        STX_HIP(copy_image_h2d(dsrc, p, img0, stride, (size_t)w, (size_t)h, s));
+        STX_HIP(copy_image_h2d(dsrc + img, p, img1, stride, (size_t)w, (size_t)h, s));
+    }
     float hinv[18];
     memcpy(hinv, Hinv0, 9 * sizeof(float));
     memcpy(hinv + 9, Hinv1, 9 * sizeof(float));
     // zero-initialised destinations (Mat::zeros, main.cpp:362,366): misses are written as 0
     rc = stx_rectify_u8_dev(ctx, dsrc, w, h, p, img, drect, w, h, p, img, hinv, 2, STX_RECT_DST_IS_ZERO);
     if (rc) return rc;
+    if (pipe) STX_HIP(hipEventRecord(ctx->ev_k[1], s));  // the rectified images may leave while the scan runs
     rc = stx_launch_disparity(ctx, drect, drect + img, 1, w, h, p, 0, 0, h, win, max_disp, cost_mode, dout, p,
                               0, 1);
     if (rc) return rc;
+    if (pipe) {
+        uint8_t *pin_out = (uint8_t *)ctx->pin_ptr[1];
+        STX_HIP(hipEventRecord(ctx->ev_k[0], s));
+        int slot = 1;
+        const int s0 = rect0 ? slot++ : 0, s1 = rect1 ? slot++ : 0;
+        if (rect0) {
+            rc = stx_host_download_begin(ctx, pin_out + (size_t)s0 * img, drect, img, ctx->ev_k[1], ctx->ev_out[s0]);
+            if (rc) return rc;
+        }
+        if (rect1) {
+            rc = stx_host_download_begin(ctx, pin_out + (size_t)s1 * img, drect + img, img, ctx->ev_k[1], ctx->ev_out[s1]);
+            if (rc) return rc;
+        }
+        rc = stx_host_download_begin(ctx, pin_out, dout, img, ctx->ev_k[0], ctx->ev_out[0]);
+        if (rc) return rc;
+        if (rect0) {
+            rc = stx_host_download_end(ctx, rect0, rect_stride, pin_out + (size_t)s0 * img, p, (size_t)h, ctx->ev_out[s0]);
+            if (rc) return rc;
+        }
+        if (rect1) {
+            rc = stx_host_download_end(ctx, rect1, rect_stride, pin_out + (size_t)s1 * img, p, (size_t)h, ctx->ev_out[s1]);
+            if (rc) return rc;
+        }
+        return stx_host_download_end(ctx, out, out_stride, pin_out, p, (size_t)h, ctx->ev_out[0]);
+    }
     STX_HIP(copy_image_d2h(out, out_stride, dout, p, (size_t)w, (size_t)h, s));
     if (rect0) STX_HIP(copy_image_d2h(rect0, rect_stride, drect, p, (size_t)w, (size_t)h, s));
     if (rect1) STX_HIP(copy_image_d2h(rect1, rect_stride, drect + img, p, (size_t)w, (size_t)h, s));
@@ -468,7 +534,7 @@ extern "C" int stx_fast_detect_u8_dev(stx_ctx *ctx, const uint8_t *d_img, int w,
     if (!ctx || !d_count || max_out < 0 || (max_out > 0 && !d_xy)) return STX_ERR_INVALID_ARG;
     int rc = check_image(d_img, w, h, stride);
     if (rc) return rc;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     if (w == 0 || h == 0) return (int)hipMemsetAsync(d_count, 0, sizeof(int), ctx->stream);
     return stx_launch_fast(ctx, d_img, w, h, stride, threshold, d_xy, max_out, d_count);
 }
@@ -481,7 +547,7 @@ extern "C" int stx_fast_detect_u8(stx_ctx *ctx, const uint8_t *img, int w, int h
     if (rc) return rc;
     *count = 0;
     if (w == 0 || h == 0) return STX_OK;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     int err;
     hipStream_t s = ctx->stream;
     const size_t p = (size_t)w;
@@ -532,7 +598,7 @@ extern "C" int stx_score_cluster_dev(stx_ctx *ctx, const uint8_t *d_gx, const ui
     if (rc) return rc;
     rc = check_image(d_gy, w, h, stride);
     if (rc) return rc;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     return stx_launch_score_cluster(ctx, d_gx, d_gy, w, h, stride, d_xy, n, kernel3x3, score_threshold,
                                     cluster_dist, d_xy_out, d_score_out, d_index_out, d_count);
 }
@@ -550,7 +616,7 @@ extern "C" int stx_score_cluster(stx_ctx *ctx, const uint8_t *gx, const uint8_t 
     if (rc) return rc;
     *count = 0;
     if (n == 0) return STX_OK;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     int err;
     hipStream_t s = ctx->stream;
     const size_t p = (size_t)(w > 0 ? w : 1), img = (p * (size_t)(h > 0 ? h : 1) + 15) & ~(size_t)15;
@@ -589,7 +655,7 @@ extern "C" int stx_cluster_features_dev(stx_ctx *ctx, const float *d_xy, const f
 {
     if (!ctx || !d_count || n < 0) return STX_ERR_INVALID_ARG;
     if (n > 0 && (!d_xy || !d_score || !d_index_out)) return STX_ERR_INVALID_ARG;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     return stx_launch_cluster(ctx, d_xy, d_score, n, (float)window, d_index_out, d_count);
 }
 
@@ -600,7 +666,7 @@ extern "C" int stx_cluster_features(stx_ctx *ctx, const float *xy, const float *
     if (n > 0 && (!xy || !score || !index_out)) return STX_ERR_INVALID_ARG;
     *count = 0;
     if (n == 0) return STX_OK;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     int err;
     hipStream_t s = ctx->stream;
     // [xy n*2][score n][index n][count]
@@ -633,7 +699,7 @@ extern "C" int stx_sift_descriptors_dev(stx_ctx *ctx, const uint8_t *d_gx, const
     if (rc) return rc;
     rc = check_image(d_gy, w, h, stride);
     if (rc) return rc;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     return stx_launch_sift(ctx, d_gx, d_gy, w, h, stride, d_xy, n, d_angle, d_desc);
 }
 
@@ -647,7 +713,7 @@ extern "C" int stx_sift_descriptors(stx_ctx *ctx, const uint8_t *gx, const uint8
     rc = check_image(gy, w, h, stride);
     if (rc) return rc;
     if (n == 0) return STX_OK;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     int err;
     hipStream_t s = ctx->stream;
     const size_t p = (size_t)(w > 0 ? w : 1), img = (p * (size_t)(h > 0 ? h : 1) + 15) & ~(size_t)15;
@@ -690,7 +756,7 @@ extern "C" int stx_ransac_score_dev(stx_ctx *ctx, const float *hyp, int n_hyp, c
 {
     int rc = check_ransac_args(ctx, hyp, n_hyp, K1, K2, d_p1, d_p2, n, d_inliers, d_err_sum);
     if (rc) return rc;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     return stx_launch_ransac_score(ctx, hyp, n_hyp, K1, K2, d_p1, d_p2, n, exclude, threshold, d_inliers,
                                    d_err_sum, d_errors, d_depths);
 }
@@ -702,7 +768,7 @@ extern "C" int stx_ransac_score(stx_ctx *ctx, const float *hyp, int n_hyp, const
     int rc = check_ransac_args(ctx, hyp, n_hyp, K1, K2, p1, p2, n, inliers, err_sum);
     if (rc) return rc;
     if (n_hyp == 0) return STX_OK;
-    STX_HIP(hipSetDevice(ctx->device));
+    STX_ENTER(ctx);
     int err;
     hipStream_t s = ctx->stream;
     const size_t np = (size_t)n, nh = (size_t)n_hyp, cells = nh * np;

@@ -29,6 +29,9 @@ enum stx_slot {
     STX_SLOT_COUNT
 };
 
+struct stx_host_pool;  // stx_host.hip: worker threads for the host-pointer staging copies
+#define STX_HOST_MAX_CHUNKS 8
+
 struct stx_ctx {
     int device;
     hipStream_t stream;
@@ -37,11 +40,72 @@ struct stx_ctx {
     int num_cus;
     void *slot_ptr[STX_SLOT_COUNT];
     size_t slot_bytes[STX_SLOT_COUNT];
+    // Host-pointer entry points: pinned staging (grow-only), a second stream and events for
+    // the chunked upload / compute / download pipeline, worker threads for the host copies.
+    void *pin_ptr[2];  // [0] uploads, [1] downloads
+    size_t pin_bytes[2];
+    hipStream_t s_in, s_out;  // upload / download streams (kernels stay on `stream`)
+    hipEvent_t ev_in[STX_HOST_MAX_CHUNKS], ev_k[STX_HOST_MAX_CHUNKS], ev_out[STX_HOST_MAX_CHUNKS];
+    stx_host_pool *pool;
+    int host_pipeline;  // 1 on, 0 plain hipMemcpyAsync of the caller's buffers, -1 ask the environment
+    int host_threads;   // staging threads incl. the caller (0: STX_HOST_THREADS or a default)
+    int host_chunks;    // chunks per call (0: STX_HOST_CHUNKS or by size)
 };
 
-// Returns a device buffer of at least `bytes` bytes for `slot` (grow-only;
-// growing synchronises the stream, frees and reallocates).  nullptr + *err on failure.
+// Makes ctx's device current for the calling thread and restores the caller's device when it
+// goes out of scope: an entry point never leaves the thread on another GPU than it found it on.
+struct stx_device_guard {
+    int prev;
+    int err;
+    explicit stx_device_guard(int device) : prev(-1), err(STX_OK)
+    {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) { prev = -1; }
+        if (prev != device) {
+            e = hipSetDevice(device);
+            if (e != hipSuccess) { err = (int)e; prev = -1; }
+        } else {
+            prev = -1;  // nothing to restore
+        }
+    }
+    ~stx_device_guard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    stx_device_guard(const stx_device_guard &) = delete;
+    stx_device_guard &operator=(const stx_device_guard &) = delete;
+};
+#define STX_ENTER(ctx)                       \
+    stx_device_guard stx_guard_((ctx)->device); \
+    if (stx_guard_.err) return stx_guard_.err
+
+// Returns a device buffer of at least `bytes` bytes for `slot` (grow-only; growing waits for
+// the whole device -- work enqueued on ANY stream may still use the old buffer -- then frees
+// and reallocates).  nullptr + *err on failure.
 void *stx_workspace(stx_ctx *ctx, int slot, size_t bytes, int *err);
+
+// hipFuncSetAttribute(fn, MaxDynamicSharedMemorySize, lds), issued once per (device, kernel).
+int stx_set_lds_attr(stx_ctx *ctx, const void *fn, int lds);
+
+// ---- stx_host.hip: the host-pointer data path (pinned staging, three streams, chunks) ----
+// Releases the pinned staging, copy streams, events and worker threads.
+void stx_host_release(stx_ctx *ctx);
+bool stx_host_pipeline_on(stx_ctx *ctx);
+int stx_host_prepare(stx_ctx *ctx, size_t in_bytes, size_t out_bytes);
+int stx_host_chunks(stx_ctx *ctx, size_t bytes, size_t units);
+int stx_host_fence(stx_ctx *ctx);
+int stx_host_upload(stx_ctx *ctx, void *d_dst, void *pin, const void *src, size_t spitch, size_t wbytes,
+                    size_t rows, hipEvent_t ev);
+int stx_host_download_begin(stx_ctx *ctx, void *pin, const void *d_src, size_t bytes, hipEvent_t after,
+                            hipEvent_t ev);
+int stx_host_download_end(stx_ctx *ctx, void *dst, size_t dpitch, const void *pin, size_t wbytes, size_t rows,
+                          hipEvent_t ev);
+int stx_host_upload_flat(stx_ctx *ctx, void *d_dst, const void *src, size_t bytes, size_t pin_off);
+int stx_disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int n_pairs, int w, int h,
+                       size_t stride, size_t pair_stride, int row0, int rows, int win, int max_disp,
+                       int cost_mode, void *out, size_t out_stride, size_t out_pair_stride, int out_bytes);
+int stx_rectify_host(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h, size_t src_stride, uint8_t *dst,
+                     int dst_w, int dst_h, size_t dst_stride, const float Hinv[9], int flags);
 
 #define STX_HIP(call)                                   \
     do {                                                \
@@ -50,11 +114,13 @@ void *stx_workspace(stx_ctx *ctx, int slot, size_t bytes, int *err);
     } while (0)
 
 // Kernel launchers (device pointers, asynchronous on ctx->stream).
+// keys/keys_bytes: caller-provided buffer for the per-pixel keys carried between passes
+// (D > 256); nullptr = take it from the context's grow-only workspace.
 int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_img1,
                          int n_pairs, int w, int h, size_t stride, size_t pair_stride,
                          int row0, int rows, int win, int max_disp, int cost_mode,
                          void *d_out, size_t out_stride, size_t out_pair_stride,
-                         int out_bytes);
+                         int out_bytes, void *keys = nullptr, size_t keys_bytes = 0);
 
 int stx_launch_rectify(stx_ctx *ctx, const uint8_t *d_src, int src_w, int src_h,
                        size_t src_stride, size_t src_image_stride, uint8_t *d_dst,

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_error_strings():
     from stereo_amd import _lib
     lib = _lib.load_library()
-    assert lib.stx_version() == 100
+    assert lib.stx_version() == 200
     assert lib.stx_error_string(0) == b"ok"
     assert b"invalid argument" in lib.stx_error_string(-1)
     assert b"unsupported" in lib.stx_error_string(-2)
@@ -55,6 +55,16 @@ def test_null_context_is_rejected_without_touching_a_gpu():
     assert lib.stx_ransac_score_dev(None, None, 0, None, None, None, None, 0, None, C.c_float(70), None, None, None,
                                     None) == -1
     assert lib.stx_rectify_disparity_u8(None, None, None, 4, 4, 4, None, None, 1, 0, 0, None, 4, None, None, 4) == -1
+    # the multi-device handle and the host pipeline switch
+    assert lib.stx_set_host_pipeline(None, 1, 0, 0) == -1
+    assert lib.stx_multi_size(None) == -1
+    assert lib.stx_multi_context(None, 0) is None
+    assert lib.stx_multi_create(None, None, 0) == -1
+    assert lib.stx_disparity_batch_u8(None, None, None, 1, 4, 4, 4, 16, 1, 0, 0, None, 4, 16) == -1
+    assert lib.stx_disparity_rowband_u8(None, None, None, 4, 4, 4, 1, 0, 0, None, 4) == -1
+    assert lib.stx_disparity_rowband_u16(None, None, None, 4, 4, 4, 1, 0, 0, None, 8) == -1
+    assert lib.stx_match_multi(None, None, None, 0, None, None, 0, C.c_float(1.0), None, None, None, None, None) == -1
+    lib.stx_multi_destroy(None)  # a no-op
 
 
 def test_invert_homography_matches_oracle_bit_for_bit(oracle):

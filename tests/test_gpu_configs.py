@@ -1,0 +1,364 @@
+"""BASELINE.json's configurations at their own sizes, the host-pointer data path, and the
+multi-device handle -- all through the C ABI on a real MI355X.
+
+config 1  features -> F -> rectify -> disparity as ONE chain (741x500 synthetic stand-in for the
+          Middlebury Motorcycle quarter-res pair, which is not in the image)
+config 4  the real launch: 1024 1080p pairs, 192 disparities, one batched call
+config 5  200 000 x 200 000 descriptors at full size
+(config 2 and config 3 at full size are in test_gpu_parity.py.)
+"""
+import os
+
+import numpy as np
+import pytest
+
+from stereo_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _match_equal(got, want):
+    names = ["closest", "second", "min_dist", "second_dist", "status"]
+    for n, g, w in zip(names, got, want):
+        g, w = np.asarray(g), np.asarray(w)
+        if g.dtype == np.float32:
+            ok = (g.view(np.uint32) == w.view(np.uint32)) | (np.isnan(g) & np.isnan(w))
+            assert ok.all(), "%s differs at %s" % (n, np.nonzero(~ok)[0][:8])
+        else:
+            assert g.tobytes() == w.tobytes(), "%s differs at %s" % (n, np.nonzero(g != w)[0][:8])
+
+
+# ------------------------------------------------------------------ config 5 ----
+
+def test_config5_full_size_200k_x_200k(ctx, oracle):
+    """BASELINE config 5 at its own size.  The x1 prefilter's schedule depends on the size (pieces
+    per query block, padding to 32 tiles, XCD-aligned ranges), so the 200k x 200k launch itself is
+    checked: all five outputs of a strided sample of 2048 queries against the exact GPU scan of
+    those queries over the whole list2, and 64 of them against the CPU oracle."""
+    import torch
+    n = 200_000
+    d1, s1, d2, s2 = synth.descriptor_sets(42, n, n)
+    dev = torch.device("cuda", 0)
+    td1, ts1 = torch.from_numpy(d1).to(dev), torch.from_numpy(s1).to(dev)
+    td2, ts2 = torch.from_numpy(d2).to(dev), torch.from_numpy(s2).to(dev)
+
+    def outs(m):
+        return (torch.empty(m, dtype=torch.int32, device=dev), torch.empty(m, dtype=torch.int32, device=dev),
+                torch.empty(m, dtype=torch.float32, device=dev), torch.empty(m, dtype=torch.float32, device=dev),
+                torch.empty(m, dtype=torch.uint8, device=dev))
+
+    full = outs(n)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.set_match_algo(api.MATCH_MFMA_BF16X1)
+        ctx.match_dev(td1, ts1, td2, ts2, 1000.0, *full)
+        torch.cuda.synchronize()
+        idx = np.unique(np.concatenate([np.arange(0, n, 97)[:2040], [0, 1, 511, 512, 513, n - 513, n - 2, n - 1]]))
+        tidx = torch.from_numpy(idx).to(dev)
+        sd1, ss1 = td1[tidx].contiguous(), ts1[tidx].contiguous()
+        ex = outs(len(idx))
+        ctx.set_match_algo(api.MATCH_EXACT)
+        ctx.match_dev(sd1, ss1, td2, ts2, 1000.0, *ex)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_match_algo(api.MATCH_AUTO)
+        ctx.set_stream(0)
+    got = [t.cpu().numpy() for t in full]
+    want = [t.cpu().numpy() for t in ex]
+    assert len(idx) >= 2000
+    _match_equal([g[idx] for g in got], want)
+    sub = idx[:: len(idx) // 64][:64]
+    _match_equal([g[sub] for g in got], oracle.match(d1[sub], s1[sub], d2, s2, 1000.0))
+    # the workload is what BASELINE names: about half of list2 are noisy copies of list1 rows
+    acc = int((got[4] == api.MATCH_ACCEPTED).sum())
+    assert 0.2 * n < acc < 0.6 * n
+    # AUTO picks the same kernel at this size: same bytes
+    auto = outs(n)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.match_dev(td1, ts1, td2, ts2, 1000.0, *auto)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_stream(0)
+    for a, b in zip(auto, full):
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+
+
+# ------------------------------------------------------------------ config 4 ----
+
+def test_config4_real_launch_1024_pairs(ctx, oracle):
+    """BASELINE config 4's actual launch: 1024 pairs in one batched call (grid z = 1024, 2 GB
+    per input array), four distinct pairs repeated as in bench.py.  Every one of the 1024 maps
+    must equal the single-call map of its pair (compared on the device); the single-call maps are
+    checked against the oracle on sampled rows."""
+    import torch
+    h, w, D, win, n, distinct = 1080, 1920, 192, 9, 1024, 4
+    pairs = [synth.rectified_pair(400 + k, h, w, D) for k in range(distinct)]
+    dev = torch.device("cuda", 0)
+    a4 = torch.from_numpy(np.stack([p[0] for p in pairs])).to(dev)
+    b4 = torch.from_numpy(np.stack([p[1] for p in pairs])).to(dev)
+    a = a4.repeat(n // distinct, 1, 1)
+    b = b4.repeat(n // distinct, 1, 1)
+    out = torch.empty_like(a)
+    single = torch.empty_like(a4)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.disparity_dev(a, b, out, win=win, max_disp=D)
+        for k in range(distinct):
+            ctx.disparity_dev(a4[k], b4[k], single[k], win=win, max_disp=D)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_stream(0)
+    same = (out.view(n // distinct, distinct, h, w) == single.unsqueeze(0)).all()
+    assert bool(same.item())
+    sg = single.cpu().numpy()
+    rr = win // 2
+    for k in range(distinct):
+        l, r = pairs[k]
+        for y0 in (0, 537, h - 4):
+            b0, b1 = max(0, y0 - rr), min(h, y0 + 4 + rr)
+            want = oracle.disparity_ext(l[b0:b1], r[b0:b1], win, D, 0, sliding=True)
+            assert (sg[k][y0:y0 + 4] == want[y0 - b0:y0 - b0 + 4]).all()
+
+
+# ------------------------------------------------------------------ config 1 ----
+
+def _cv8u_gradients(img):
+    """Stand-ins for the CV_8U GaussianBlur + Sobel images the reference makes with OpenCV
+    (Features.cpp:684-690; third-party arithmetic, out of scope): a 3x3 box blur and central
+    differences, negative values clipped to 0 as ddepth = CV_8U does.  What matters here is that
+    they are functions of the image, so the two views' descriptors correspond."""
+    f = img.astype(np.float32)
+    p = np.pad(f, 1, mode="edge")
+    blur = sum(p[dy:dy + f.shape[0], dx:dx + f.shape[1]] for dy in range(3) for dx in range(3)) / 9.0
+    q = np.pad(blur, 1, mode="edge")
+    gx = q[1:-1, 2:] - q[1:-1, :-2]
+    gy = q[2:, 1:-1] - q[:-2, 1:-1]
+    return (np.clip(gx * 4, 0, 255).astype(np.uint8), np.clip(gy * 4, 0, 255).astype(np.uint8))
+
+
+def test_config1_whole_chain_on_the_741x500_stand_in(ctx, oracle):
+    """BASELINE config 1 as a chain (main.cpp:188-380): FAST -> score + NMS -> descriptors for both
+    images -> MatchDescriptors -> FindFundamentalMatrixWithRANSAC -> RectifyImage x2 ->
+    ComputeDepthImage, every stage on the GPU and every stage compared with the same chain through
+    the oracle.  Stand-ins, stated: the image pair is synthetic (741x500, the Motorcycle
+    quarter-res size; the dataset is not in the image); the gradient images come from
+    _cv8u_gradients instead of OpenCV; ComputeRectificationRotations (Eigen BDCSVD + SO(3) log/exp,
+    host code that stays the reference's) is replaced by a fixed seeded pair of K R K^-1."""
+    from stereo_amd import ransac
+    h, w = 500, 741
+    left, right = synth.rectified_pair(1001, h, w, 48, zero_frac=0.0)
+    stages = []
+    for img in (left, right):
+        gx, gy = _cv8u_gradients(img)
+        feats = []
+        assert api.FindFASTFeatures(img, feats, ctx=ctx)
+        oxy = oracle.fast_features(img)
+        assert [f.p for f in feats] == [tuple(map(float, p)) for p in oxy]
+        feats = api.ScoreAndClusterFeatures(gx, gy, feats, api.ST_THRESH, api.NMS_WINDOW, ctx=ctx)
+        sxy, ssc, _ = oracle.score_and_cluster(gx, gy, oxy, oracle.gaussian_kernel(3, 1.0), 700.0, 2.0)
+        assert [f.p for f in feats] == [tuple(map(float, p)) for p in sxy]
+        assert np.array([f.score for f in feats], np.float32).tobytes() == ssc.tobytes()
+        descs = []
+        assert api.CreateSIFTDescriptors(gx, gy, feats, descs, ctx=ctx)
+        oang, odesc = oracle.sift_descriptors(gx, gy, sxy)
+        gd = np.stack([f.desc for f in feats])
+        assert ((gd.view(np.uint32) == odesc.view(np.uint32)) | (np.isnan(gd) & np.isnan(odesc))).all()
+        stages.append((feats, sxy, ssc, odesc))
+    n1, n2 = len(stages[0][0]), len(stages[1][0])
+    assert n1 > 100 and n2 > 100
+
+    # MatchDescriptors (main.cpp:207)
+    matches = api.MatchDescriptors(stages[0][0], stages[1][0], 1000.0, ctx=ctx, out=open(os.devnull, "w"))
+    want = oracle.match(stages[0][3], stages[0][2], stages[1][3], stages[1][2], 1000.0)
+    acc = np.nonzero(want[4] == api.MATCH_ACCEPTED)[0]
+    assert len(matches) == len(acc) and len(acc) >= 30
+    p1 = np.array([m[0].p for m in matches], np.float32)
+    p2 = np.array([m[1].p for m in matches], np.float32)
+    assert p1.tobytes() == stages[0][1][acc].astype(np.float32).tobytes()
+    assert p2.tobytes() == stages[1][1][want[0][acc]].astype(np.float32).tobytes()
+    assert np.array([m[0].distFromBestMatch for m in matches], np.float32).tobytes() == want[2][acc].tobytes()
+
+    # FindFundamentalMatrixWithRANSAC (main.cpp:220): GPU-scored loop vs oracle-scored loop
+    f = 3979.911 / 4
+    K = np.array([[f, 0, 311.0], [0, f, 255.0], [0, 0, 1]], np.float32)   # Middlebury calib / 4
+
+    class OracleScorer:
+        def ransac_score(self, recs, a, b, q1, q2, exclude=None):
+            return oracle.ransac_score(recs, a, b, q1, q2, exclude)[:2]
+
+    ok_g, f_g = ransac.FindFundamentalMatrixWithRANSAC(p1, p2, K, K, seed=7, ctx=ctx)
+    ok_o, f_o = ransac.FindFundamentalMatrixWithRANSAC(p1, p2, K, K, seed=7, ctx=OracleScorer())
+    assert ok_g == ok_o
+    if ok_g:
+        assert np.array_equal(f_g, f_o)
+
+    # RectifyImage x2 + ComputeDepthImage (main.cpp:362-380), reference mode and a windowed scan
+    H0 = synth.homography(5, w, h, deg_y=0.8, deg_x=0.2)
+    H1 = synth.homography(6, w, h, deg_y=-0.6, deg_x=0.3)
+    i0, i1 = oracle.invert3x3(H0), oracle.invert3x3(H1)
+    assert ctx.invert_homography(H0).tobytes() == i0.astype(np.float32).tobytes()
+    r0 = oracle.rectify(left, np.zeros((h, w), np.uint8), i0)
+    r1 = oracle.rectify(right, np.zeros((h, w), np.uint8), i1)
+    g0, g1 = np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8)
+    api.RectifyImage(left, g0, H0, ctx=ctx)
+    api.RectifyImage(right, g1, H1, ctx=ctx)
+    assert (g0 == r0).all() and (g1 == r1).all()
+    depth = api.ComputeDepthImage(g0, g1, ctx=ctx)
+    assert (depth == oracle.disparity_ref(r0, r1)).all()
+    for win, D in [(1, 0), (9, 64)]:
+        wantd = oracle.disparity_ext(r0, r1, win, D, 0)
+        got, f0, f1 = ctx.rectify_disparity(left, right, i0, i1, win=win, max_disp=D, want_rectified=True)
+        assert (f0 == r0).all() and (f1 == r1).all() and (got == wantd).all()
+    assert (depth != 0).any()
+
+
+# ------------------------------------------------------------- N4 on the GPU ----
+
+def test_descriptor_file_replayed_through_stx_match(ctx, oracle, tmp_path):
+    """a descriptor cache file in the reference's text format (Features.h:62-142,
+    Features.cpp:1219-1276) is written, read back and its two feature lists matched through
+    stx_match; the oracle matches the same read-back values.  (The text keeps 6 significant
+    digits, as the reference's operator<< does, so the read-back descriptors are what is matched.)
+    No file written by the reference itself exists to pin the format against."""
+    from stereo_amd import featfile
+    d1, s1, d2, s2 = synth.descriptor_sets(91, 400, 500)
+    imgs = []
+    for name, d, s in (("im0.png", d1, s1), ("im1.png", d2, s2)):
+        feats = [api.Feature(scale=1, p=(float(i % 37) + 0.5, float(i // 37)), score=float(s[i]), angle=float(i % 90),
+                             desc=d[i]) for i in range(len(d))]
+        imgs.append(featfile.ImageDescriptor(name, 741, 500, np.eye(3, dtype=np.float32),
+                                             np.eye(3, dtype=np.float32), feats))
+    path = str(tmp_path / "features.txt")
+    assert featfile.SaveImageDescriptorsToFile(path, imgs)
+    back = featfile.ReadDescriptorsFromFile(path)
+    assert len(back) == 2 and len(back[0].features) == 400 and len(back[1].features) == 500
+    rd1 = np.stack([f.desc for f in back[0].features])
+    rd2 = np.stack([f.desc for f in back[1].features])
+    rs1 = np.array([f.score for f in back[0].features], np.float32)
+    rs2 = np.array([f.score for f in back[1].features], np.float32)
+    assert np.abs(rd1 - d1).max() < 1e-6 and not np.array_equal(rd1, d1)
+    want = oracle.match(rd1, rs1, rd2, rs2, 1000.0)
+    _match_equal(ctx.match(rd1, rs1, rd2, rs2, 1000.0), want)
+    matches = api.MatchDescriptors(back[0].features, back[1].features, 1000.0, ctx=ctx,
+                                   out=open(os.devnull, "w"))
+    acc = np.nonzero(want[4] == api.MATCH_ACCEPTED)[0]
+    assert len(matches) == len(acc) > 50
+    assert [m[1].p for m in matches] == [back[1].features[int(want[0][i])].p for i in acc]
+
+
+# ------------------------------------------------- the host-pointer data path ----
+
+@pytest.mark.parametrize("threads,chunks", [(1, 1), (4, 0), (3, 8), (8, 3)])
+def test_host_pipeline_equals_plain_copies(ctx, oracle, threads, chunks):
+    """The pinned-staging / chunked pipeline and the plain-copy path give identical bytes: pitched
+    and dense images, reference mode, windowed scans with one and several passes, u16, the warp
+    with kept destination pixels, the fused call, matching."""
+    rng = np.random.RandomState(threads * 10 + chunks)
+    h, w = 333, 1500
+    l, r = synth.rectified_pair(3, h, w, 300)
+    lp = np.zeros((h, w + 52), np.uint8)[:, :w]
+    rp = np.zeros((h, w + 52), np.uint8)[:, :w]
+    lp[:], rp[:] = l, r
+    src = synth.texture(5, h, w)
+    Hinv = oracle.invert3x3(synth.homography(3, w, h))
+    dst0 = rng.randint(0, 255, (h, w)).astype(np.uint8)
+    d1, s1, d2, s2 = synth.descriptor_sets(9, 3000, 2500)
+
+    def run():
+        res = [ctx.disparity(l, r), ctx.disparity(lp, rp, win=9, max_disp=64),
+               ctx.disparity(l, r, win=5, max_disp=300, out_dtype=np.uint16),
+               ctx.disparity(l[:1], r[:1], win=3, max_disp=8), ctx.disparity(l[:70], r[:70], win=15, max_disp=40)]
+        d = dst0.copy()
+        ctx.rectify(src, d, Hinv, api.RECT_PRESERVE_DST)
+        res.append(d)
+        dz = np.zeros((h + 7, w - 9), np.uint8)
+        ctx.rectify(src, dz, Hinv, api.RECT_DST_IS_ZERO)
+        res.append(dz)
+        res.extend(ctx.rectify_disparity(l, r, Hinv, Hinv, win=7, max_disp=32, want_rectified=True))
+        res.append(ctx.rectify_disparity(l, r, Hinv, Hinv))
+        res.extend(ctx.match(d1, s1, d2, s2, 1000.0))
+        return res
+
+    try:
+        ctx.set_host_pipeline(False)
+        plain = run()
+        ctx.set_host_pipeline(True, threads, chunks)
+        piped = run()
+        again = run()
+    finally:
+        ctx.set_host_pipeline(True, 0, 0)
+    for a, b, c in zip(plain, piped, again):
+        assert a.tobytes() == b.tobytes() == c.tobytes()
+    assert (plain[0] == oracle.disparity_ref(l, r)).all()
+    assert (plain[1] == oracle.disparity_ext(l, r, 9, 64, 0)).all()
+    assert (plain[5] == oracle.rectify(src, dst0.copy(), Hinv)).all()
+
+
+def test_entry_points_leave_the_callers_device_alone(ctx):
+    """Every entry point restores the thread's current device (one GPU here: it must stay 0 and
+    torch must keep working between calls)."""
+    import torch
+    l, r = synth.rectified_pair(1, 20, 100, 8)
+    before = torch.cuda.current_device()
+    ctx.disparity(l, r, win=3, max_disp=8)
+    t = torch.ones(4, device="cuda") * 2
+    assert torch.cuda.current_device() == before and float(t.sum().item()) == 8.0
+
+
+# ------------------------------------------------------- several GPUs, one process ----
+
+def _device_counts():
+    import stereo_amd
+    n = int(stereo_amd.load_library().stx_device_count())
+    return [1] + ([2] if n >= 2 else []) + ([n] if n > 2 else [])
+
+
+def test_multi_device_handle_matches_single_calls(ctx, oracle):
+    """stx_multi_*: pairs dealt to the devices, one pair cut into row bands with halo, queries
+    sharded -- each bit-equal to the single-context call (n = 1 here on a one-GPU box; n = 2 and
+    n = all where the box has them)."""
+    from stereo_amd import MultiContext
+    pairs = [synth.rectified_pair(50 + k, 90, 410, 40) for k in range(5)]
+    a = np.stack([p[0] for p in pairs])
+    b = np.stack([p[1] for p in pairs])
+    big_l, big_r = synth.rectified_pair(60, 301, 900, 300)
+    d1, s1, d2, s2 = synth.descriptor_sets(12, 2500, 3000)
+    want_batch = np.stack([ctx.disparity(p[0], p[1], win=9, max_disp=40) for p in pairs])
+    assert (want_batch[2] == oracle.disparity_ext(pairs[2][0], pairs[2][1], 9, 40, 0)).all()
+    want_ref = ctx.disparity(big_l, big_r)
+    want_w8 = ctx.disparity(big_l, big_r, win=11, max_disp=64)
+    want_w16 = ctx.disparity(big_l, big_r, win=9, max_disp=300, out_dtype=np.uint16)
+    want_ssd = ctx.disparity(big_l, big_r, win=5, max_disp=32, cost_mode=api.COST_SSD)
+    want_m = ctx.match(d1, s1, d2, s2, 1000.0)
+    for n in _device_counts():
+        m = MultiContext(list(range(n)))
+        try:
+            assert m.size == n
+            assert (m.disparity_batch(a, b, win=9, max_disp=40) == want_batch).all()
+            assert (m.disparity_batch(a[:1], b[:1], win=9, max_disp=40) == want_batch[:1]).all()
+            assert (m.disparity_rowbands(big_l, big_r) == want_ref).all()
+            assert (m.disparity_rowbands(big_l, big_r, win=11, max_disp=64) == want_w8).all()
+            assert (m.disparity_rowbands(big_l, big_r, win=9, max_disp=300, out_dtype=np.uint16) == want_w16).all()
+            assert (m.disparity_rowbands(big_l, big_r, win=5, max_disp=32, cost_mode=api.COST_SSD) == want_ssd).all()
+            assert (m.disparity_rowbands(big_l[:3], big_r[:3], win=9, max_disp=16)
+                    == ctx.disparity(big_l[:3], big_r[:3], win=9, max_disp=16)).all()
+            _match_equal(m.match(d1, s1, d2, s2, 1000.0), want_m)
+            _match_equal(m.match(d1[:1], s1[:1], d2, s2, 1000.0), [x[:1] for x in want_m])
+        finally:
+            m.close()
+
+
+def test_multi_device_argument_errors():
+    from stereo_amd import MultiContext, StereoHipError
+    with pytest.raises(StereoHipError):
+        MultiContext([0, 0])          # a device twice
+    with pytest.raises(StereoHipError):
+        MultiContext([99])            # no such device
+    m = MultiContext([0])
+    try:
+        a = np.ones((2, 4, 4), np.uint8)
+        with pytest.raises(StereoHipError):
+            m.disparity_batch(a, a, win=4, max_disp=4)
+    finally:
+        m.close()
