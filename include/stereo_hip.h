@@ -190,6 +190,22 @@ int stx_disparity_dev(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_img1
                       int win, int max_disp, int cost_mode, void *d_out,
                       size_t out_stride, size_t out_pair_stride, int out_bytes);
 
+/* The same scan for callers that cannot allocate: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.  Arguments and
+ * results are exactly stx_disparity_dev's.  The one scratch buffer the scan needs -- the
+ * per-pixel keys carried between passes when more than 256 disparities are searched -- is a
+ * static device array inside the library, so this call never calls hipMalloc / hipFree (nor any
+ * allocating library routine).  Limit: a scan of more than 256 disparities may cover at most
+ * STX_NOALLOC_MAX_PIXELS pixels (n_pairs * w * h; one 3840x2160 pair fits), else
+ * STX_ERR_TOO_LARGE; scans of up to 256 disparities need no scratch and have no such limit.
+ * Every call on one GPU shares that GPU's array (32 MiB, held until the process ends): calls
+ * that overlap on one GPU -- from any context or stream -- race.  Asynchronous. */
+#define STX_NOALLOC_MAX_PIXELS (1 << 23)
+int stx_disparity_dev_noalloc(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_img1,
+                              int n_pairs, int w, int h, size_t stride, size_t pair_stride,
+                              int win, int max_disp, int cost_mode, void *d_out,
+                              size_t out_stride, size_t out_pair_stride, int out_bytes);
+
 /* Row-band form for sharding one large pair over several GPUs:
  * computes output rows [row0, row0+rows) only; img pointers and h describe the
  * rows this process holds, [band_row0, band_row0+h) of the full image, which

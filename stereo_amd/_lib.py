@@ -4,7 +4,9 @@ The library is the product; this module only declares its prototypes.  If the
 shared object is missing the loader raises -- there is no fallback path.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -75,6 +77,9 @@ PROTOTYPES = {
     "stx_disparity_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t,
                                     C.c_size_t, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t,
                                     C.c_size_t, C.c_int]),
+    "stx_disparity_dev_noalloc": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t,
+                                            C.c_size_t, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t,
+                                            C.c_size_t, C.c_int]),
     "stx_fast_detect_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, C.c_int, _vp, C.c_int,
                                      C.POINTER(C.c_int)]),
     "stx_fast_detect_u8_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, C.c_int, _vp, C.c_int, _vp]),
@@ -100,6 +105,36 @@ PROTOTYPES = {
 }
 
 
+def _bind_to_torchs_hip_runtime():
+    """One HIP runtime per process.
+
+    libstereo_hip.so needs `libamdhip64.so.7` (RUNPATH /opt/rocm); torch's wheel ships its own
+    runtime as torch/lib/libamdhip64.so -- a different FILE NAME with the SAME soname
+    (libamdhip64.so.7), plus its own libhsa-runtime64.  The dynamic loader matches a request
+    against the sonames of what is already loaded, so:
+      torch first:  our request for libamdhip64.so.7 resolves to torch's copy -- one runtime;
+      ours first:   /opt/rocm's copy is loaded, and torch's later request for the file name
+                    `libamdhip64.so` matches nothing loaded, so a SECOND HIP runtime and a second
+                    HSA runtime come up in the process and torch finds "No HIP GPUs".
+    Loading torch's copy (globally) before ours makes both orders the first case.  It only
+    locates the file; torch itself is not imported.  STEREO_HIP_RUNTIME=system skips this (a
+    process that will never load torch); a host program without torch gets /opt/rocm's runtime
+    through the RUNPATH as usual."""
+    if os.environ.get("STEREO_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return None
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return None
+    if spec is None or not spec.origin:
+        return None
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return path
+
+
 def load_library():
     """Load libstereo_hip.so once and attach prototypes.  Raises if it is absent."""
     global _LIB
@@ -111,6 +146,7 @@ def load_library():
             "libstereo_hip.so not found at %s -- build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C stereo_amd/csrc`.  stereo_amd has no CPU fallback." % path)
+    _bind_to_torchs_hip_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

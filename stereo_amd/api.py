@@ -39,6 +39,7 @@ COST_SAD, COST_SSD = 0, 1
 RECT_PRESERVE_DST, RECT_DST_IS_ZERO = 0, 1
 MATCH_AUTO, MATCH_EXACT, MATCH_MFMA, MATCH_MFMA_BF16, MATCH_MFMA_BF16X1 = 0, 1, 2, 3, 4
 DISP_AUTO, DISP_BRUTEFORCE = 0, 1
+NOALLOC_MAX_PIXELS = 1 << 23  # STX_NOALLOC_MAX_PIXELS, include/stereo_hip.h
 
 
 @dataclass
@@ -404,6 +405,21 @@ class Context:
             self._h, a.data_ptr(), b.data_ptr(), n, w, h, int(a.stride(1)), int(a.stride(0)),
             int(win), int(max_disp), int(cost_mode), o.data_ptr(), int(o.stride(1)) * ob,
             int(o.stride(0)) * ob, ob), "stx_disparity_dev")
+
+    def disparity_dev_noalloc(self, img0, img1, out, win=1, max_disp=0, cost_mode=COST_SAD):
+        """disparity_dev through the entry point that allocates nothing (static device scratch;
+        scans of more than 256 disparities are limited to NOALLOC_MAX_PIXELS pixels)."""
+        a = img0 if img0.dim() == 3 else img0.unsqueeze(0)
+        b = img1 if img1.dim() == 3 else img1.unsqueeze(0)
+        o = out if out.dim() == 3 else out.unsqueeze(0)
+        if a.shape != b.shape or a.stride() != b.stride() or o.shape != a.shape:
+            raise ValueError("img0, img1 and out must agree in shape and layout")
+        n, h, w = (int(v) for v in a.shape)
+        ob = o.element_size()
+        check(self._lib.stx_disparity_dev_noalloc(
+            self._h, a.data_ptr(), b.data_ptr(), n, w, h, int(a.stride(1)), int(a.stride(0)),
+            int(win), int(max_disp), int(cost_mode), o.data_ptr(), int(o.stride(1)) * ob,
+            int(o.stride(0)) * ob, ob), "stx_disparity_dev_noalloc")
 
     def disparity_rowband_dev(self, img0, img1, band_row0, full_h, row0, rows, out, win=1,
                               max_disp=0, cost_mode=COST_SAD):

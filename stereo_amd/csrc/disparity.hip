@@ -8,6 +8,24 @@
 // All arithmetic is integer; results are bit-exact against oracle/stereo_oracle.c.
 #include "stx_internal.h"
 
+// Scratch of stx_disparity_dev_noalloc (include/stereo_hip.h): the per-pixel keys a scan of
+// more than 256 disparities carries between its passes.  Every GPU this library runs on holds
+// its own copy of the array until the process ends.  In host code the NAME is only a stand-in
+// for hipGetSymbolAddress; kernels and copies always get the per-device address it returns.
+static __device__ __align__(256) unsigned disp_scratch[STX_NOALLOC_MAX_PIXELS];
+
+int stx_disparity_scratch(void **ptr, size_t *bytes)
+{
+    // the caller (stx_create) has made the context's device current
+    void *p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(disp_scratch));
+    if (e != hipSuccess) return (int)e;
+    if (!p) return STX_ERR_NO_DEVICE;
+    *ptr = p;
+    *bytes = sizeof(unsigned) * (size_t)STX_NOALLOC_MAX_PIXELS;
+    return STX_OK;
+}
+
 namespace {
 
 // ---------------------------------------------------------------------------

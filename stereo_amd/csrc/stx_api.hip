@@ -56,6 +56,12 @@ extern "C" int stx_create(stx_ctx **out, int device)
         return (int)e;
     }
     ctx->num_cus = prop.multiProcessorCount;
+    // this device's copy of the static scratch array behind stx_disparity_dev_noalloc
+    int rc = stx_disparity_scratch(&ctx->disp_scratch, &ctx->disp_scratch_bytes);
+    if (rc != STX_OK) {
+        delete ctx;
+        return rc;
+    }
     *out = ctx;
     return STX_OK;
 }
@@ -405,6 +411,27 @@ extern "C" int stx_disparity_dev(stx_ctx *ctx, const uint8_t *d_img0, const uint
     STX_ENTER(ctx);
     return stx_launch_disparity(ctx, d_img0, d_img1, n_pairs, w, h, stride, pair_stride, 0, h, win,
                                 max_disp, cost_mode, d_out, out_stride, out_pair_stride, out_bytes);
+}
+
+extern "C" int stx_disparity_dev_noalloc(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_img1,
+                                         int n_pairs, int w, int h, size_t stride, size_t pair_stride,
+                                         int win, int max_disp, int cost_mode, void *d_out,
+                                         size_t out_stride, size_t out_pair_stride, int out_bytes)
+{
+    if (!ctx || n_pairs < 0) return STX_ERR_INVALID_ARG;
+    int rc = check_disparity_args(w, h, stride, win, max_disp, cost_mode, out_bytes, out_stride);
+    if (rc) return rc;
+    if (n_pairs == 0 || w == 0 || h == 0) return STX_OK;
+    if (!d_img0 || !d_img1 || !d_out) return STX_ERR_INVALID_ARG;
+    if (n_pairs > 1 && (pair_stride < stride * (size_t)h || out_pair_stride < out_stride * (size_t)h))
+        return STX_ERR_INVALID_ARG;
+    if (!ctx->disp_scratch) return STX_ERR_UNSUPPORTED;
+    STX_ENTER(ctx);
+    // ctx->disp_scratch is this device's address of the static array (hipGetSymbolAddress at
+    // stx_create); the launcher rejects scans whose keys do not fit it and never allocates
+    return stx_launch_disparity(ctx, d_img0, d_img1, n_pairs, w, h, stride, pair_stride, 0, h, win,
+                                max_disp, cost_mode, d_out, out_stride, out_pair_stride, out_bytes,
+                                ctx->disp_scratch, ctx->disp_scratch_bytes);
 }
 
 static int disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int w, int h,

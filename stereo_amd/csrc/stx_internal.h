@@ -40,6 +40,10 @@ struct stx_ctx {
     int num_cus;
     void *slot_ptr[STX_SLOT_COUNT];
     size_t slot_bytes[STX_SLOT_COUNT];
+    // static device scratch of stx_disparity_dev_noalloc on this context's device
+    // (hipGetSymbolAddress at stx_create; disparity.hip), and its size in bytes
+    void *disp_scratch;
+    size_t disp_scratch_bytes;
     // Host-pointer entry points: pinned staging (grow-only), a second stream and events for
     // the chunked upload / compute / download pipeline, worker threads for the host copies.
     void *pin_ptr[2];  // [0] uploads, [1] downloads
@@ -106,6 +110,9 @@ int stx_disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, i
                        int cost_mode, void *out, size_t out_stride, size_t out_pair_stride, int out_bytes);
 int stx_rectify_host(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h, size_t src_stride, uint8_t *dst,
                      int dst_w, int dst_h, size_t dst_stride, const float Hinv[9], int flags);
+
+// disparity.hip: device address and size of this device's static scratch array.
+int stx_disparity_scratch(void **ptr, size_t *bytes);
 
 #define STX_HIP(call)                                   \
     do {                                                \

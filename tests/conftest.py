@@ -23,10 +23,8 @@ def oracle():
 @pytest.fixture(scope="session")
 def ctx():
     """A libstereo_hip context on GPU 0.  Fails loudly if the library is missing."""
-    # torch first, as in bench.py: torch ships its own HIP runtime, and initialising it after
-    # libstereo_hip.so's has been seen to fail with "No HIP GPUs are available"
-    import torch
-    torch.cuda.init()
+    # (either import order works: stereo_amd._lib binds to the HIP runtime torch ships, see
+    # _bind_to_torchs_hip_runtime and tests/test_gpu_configs.py::test_library_before_torch)
     import stereo_amd
     c = stereo_amd.Context(0)
     yield c

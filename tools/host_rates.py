@@ -1,4 +1,5 @@
-"""End-to-end (host-pointer, PCIe-inclusive) rates of the host C-ABI entry points."""
+"""End-to-end (host-pointer, PCIe-inclusive) rates of the host C-ABI entry points: the plain-copy
+path against the pinned-staging pipeline at several thread / chunk settings."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -6,24 +7,45 @@ import stereo_amd
 from stereo_amd import synth
 
 ctx = stereo_amd.Context(0)
-def best(fn, n=7):
-    fn(); ts = []
+
+
+def best(fn, n=15):
+    fn(); fn(); ts = []
     for _ in range(n):
         t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
-    return min(ts), float(np.median(ts))
+    return min(ts) * 1e3, float(np.median(ts)) * 1e3
+
 
 W, H, D = 2880, 1988, 256
 l, r = synth.rectified_pair(2024, H, W, D)
-units = (D * (W - D) + D * (D + 1) // 2) * H
-b, m = best(lambda: ctx.disparity(l, r, win=9, max_disp=D))
-print("disparity 9x9 D=256 %dx%d host API: best %.3f ms median %.3f ms -> %.3g Mpix*disp/s (HBM-resident kernel: 0.375 ms)" % (W, H, b * 1e3, m * 1e3, units / m / 1e6))
-b, m = best(lambda: ctx.disparity(l, r))
-print("disparity reference mode host API: best %.3f ms median %.3f ms -> %.3g Mpix*disp/s" % (b * 1e3, m * 1e3, W * W * H / m / 1e6))
-src = synth.texture(3, 1080, 1920); Hinv = ctx.invert_homography(synth.homography(3, 1920, 1080))
+src = synth.texture(3, 1080, 1920)
+Hinv = ctx.invert_homography(synth.homography(3, 1920, 1080))
 dst = np.zeros_like(src)
-b, m = best(lambda: ctx.rectify(src, dst, Hinv))
-print("rectify 1920x1080 host API (dst uploaded, PRESERVE): best %.3f ms median %.3f ms -> %.3g Mpix/s" % (b * 1e3, m * 1e3, 1920 * 1080 / m / 1e6))
 n = 32768
 d1, s1, d2, s2 = synth.descriptor_sets(42, n, n)
-b, m = best(lambda: ctx.match(d1, s1, d2, s2, 1000.0), 5)
-print("match %dx%d host API: best %.3f ms median %.3f ms -> %.3g descriptors/s (H2D of 2 x %.0f MB dominates)" % (n, n, b * 1e3, m * 1e3, n / m, n * 512 / 1e6))
+pairs = [synth.rectified_pair(400 + k, 1080, 1920, 192) for k in range(4)]
+ba = np.stack([p[0] for p in pairs] * 8)
+bb = np.stack([p[1] for p in pairs] * 8)
+mc = stereo_amd.MultiContext([0])
+
+settings = [("plain", None)] + [("pipe t%d c%d" % (t, c), (t, c)) for t, c in
+                                ((1, 1), (4, 1), (8, 1), (4, 2), (8, 2), (4, 4), (8, 4), (8, 8), (0, 0))]
+print("%-12s %21s %21s %21s %21s %21s %21s" % ("setting", "disp 9x9 D256 cfg2", "disp ref-mode cfg2", "rectify 1080p keep",
+                                                "rectify 1080p zero", "R+R+D fused cfg2", "match 32k x 32k"))
+for name, st in settings:
+    if st is None:
+        ctx.set_host_pipeline(False)
+    else:
+        ctx.set_host_pipeline(True, st[0], st[1])
+    row = []
+    row.append(best(lambda: ctx.disparity(l, r, win=9, max_disp=D)))
+    row.append(best(lambda: ctx.disparity(l, r), 7))
+    row.append(best(lambda: ctx.rectify(src, dst, Hinv)))
+    row.append(best(lambda: ctx.rectify(src, dst, Hinv, stereo_amd.api.RECT_DST_IS_ZERO)))
+    row.append(best(lambda: ctx.rectify_disparity(l, r, Hinv, Hinv, win=9, max_disp=D), 7))
+    row.append(best(lambda: ctx.match(d1, s1, d2, s2, 1000.0), 5))
+    print("%-12s " % name + " ".join("%8.3f / %8.3f ms" % v for v in row), flush=True)
+ctx.set_host_pipeline(True, 0, 0)
+b, m = best(lambda: mc.disparity_batch(ba, bb, win=9, max_disp=192), 5)
+print("stx_disparity_batch_u8, 32 x 1080p pairs, D=192, 1 device: best %.2f ms median %.2f ms = %.0f pairs/s" % (b, m, 32 / m * 1e3))
+print("(best / median of the calls; numpy output allocation included)")
