@@ -13,9 +13,20 @@ pair (pair sharding, no data-path collective), so scaling is weak.
 The JSON line also carries the roofline of the dominant kernel, the CPU
 baseline (oracle restatement on a bounded sample, rank 0 at N=1 only) and an
 "extra" object with the other kernels of the path (reference-mode scan,
-rectification warp, FAST-12, descriptor matching) and their CPU timings.  With
-N > 1 the matching leg shards list1 over the ranks (strong scaling of the one
-200k x 200k job); the other extras run at N = 1 only.
+rectification warp, FAST-12, descriptor matching) and their CPU timings.
+
+north_star's multi-GPU workloads run at every N (backend nccl = RCCL):
+  config 3  one 4K pair, 512 disparities: each rank scans its row band (+ halo rows from its own
+            copy of the pair), bands gathered to rank 0 by point-to-point sends   (strong scaling)
+  config 4  1024 1080p pairs, 192 disparities: 1024 / N pairs per rank, timed with and without
+            the gather of the maps to rank 0                                      (strong scaling)
+  config 5  200k x 200k matching: list1's queries sharded, list2 replicated       (strong scaling)
+Rank 0 checks every gathered result against the single-GPU result of the same input.  The other
+extras (secondary kernels, CPU timings) run at N = 1 only.
+
+Counters that cannot be measured inside this process (VALU instructions and HBM bytes per
+launch) are read from profiles/kernel_counters.json, which tools/pmc_collect.py writes from
+rocprofv3 --pmc passes over this same command; every figure derived from them names that file.
 """
 import argparse
 import json
@@ -35,6 +46,11 @@ CLOCK_HZ = 2.4e9
 # tools/ubench.hip measures 3.5e13 (3-operand integer ops such as v_sad_u32 / v_min3_u32,
 # 8 waves per SIMD, clock throttled to ~1.5 GHz under that load) to 5.2e13 (v_add_u32).
 VALU_LANEOPS = CUS * 64 * CLOCK_HZ
+# What the chip sustains on the 3-operand integer instructions these kernels are made of
+# (v_sad_u32 / v_sad_u8 / v_min3_u32 / v_or3_b32 / DPP adds), 8 waves per SIMD, all CUs:
+# profiles/r01_ubench_instruction_rates.txt (tools/ubench.hip), 2.80 cycles per instruction and
+# SIMD at the ~1.5 GHz the chip holds under that load.
+ISSUE_CEILING_WAVE_INSTR = 550e9
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_TFLOPS = 157.3
 MFMA_BF16_TFLOPS = 2500.0
@@ -57,6 +73,39 @@ def event_time_ms(torch, fn, steps, warmup):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / steps
+
+
+def load_counters():
+    """profiles/kernel_counters.json: per kernel and workload, VALU wave-instructions and HBM
+    bytes per launch from rocprofv3 --pmc passes (tools/pmc_collect.py).  {} if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "kernel_counters.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def valu_roofline(counters, key, units, ops_per_unit, ms, label=None):
+    """Roofline object of a VALU-bound kernel: the SURVEY 8(d) op model against the nominal
+    integer peak, and -- when the PMC instruction count of this workload is on file -- the
+    instructions actually issued against the measured issue ceiling."""
+    achieved = units * ops_per_unit / (ms * 1e-3)
+    r = {"bound": "valu", "achieved": achieved / 1e12, "peak": VALU_LANEOPS / 1e12, "unit": "Tlane-op/s",
+         "frac": achieved / VALU_LANEOPS, "kernel_ms": ms,
+         "model": "%g integer lane-ops per unit (SURVEY 8d) x %.4g units; peak = %d CU x 64 lanes/clk x %.1f GHz"
+                  % (ops_per_unit, units, CUS, CLOCK_HZ / 1e9)}
+    if label:
+        r["kernel"] = label
+    c = counters.get(key)
+    if c and c.get("valu_insts"):
+        rate = c["valu_insts"] / (ms * 1e-3)
+        r["issue"] = {"valu_wave_instr_per_launch": c["valu_insts"],
+                      "wave_instr_per_64_units": c["valu_insts"] / (units / 64.0),
+                      "achieved_Ginstr_per_s": rate / 1e9, "ceiling_Ginstr_per_s": ISSUE_CEILING_WAVE_INSTR / 1e9,
+                      "frac": rate / ISSUE_CEILING_WAVE_INSTR,
+                      "source": "profiles/kernel_counters.json (%s) / profiles/r01_ubench_instruction_rates.txt"
+                                % c.get("source", "?")}
+    return r
 
 
 def units_evaluated(w, h, d):
@@ -160,95 +209,54 @@ def main():
             "units_per_pair": units, "parallelism": "pairs x%d" % world,
         },
     }
-    achieved = units * OPS_PER_UNIT_WINDOWED / (kernel_ms * 1e-3)
-    out["roofline"] = {
-        "kernel": "disparity scan, %dx%d SAD, D=%d" % (WIN, WIN, D),
-        "bound": "valu",
-        "achieved": achieved / 1e12,
-        "peak": VALU_LANEOPS / 1e12,
-        "unit": "Tlane-op/s",
-        "frac": achieved / VALU_LANEOPS,
-        # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc_disp_band_kernel.md):
-        # FETCH_SIZE 12.22 MB (raw, byte loads) + WRITE_SIZE 6.15 MB; algorithmic 3 B/pixel = 17.2 MB
-        "traffic": 18.37e6,
-        "algorithmic_bytes": 3.0 * W * H,
-        "model": "%d integer lane-ops per (pixel,candidate) unit (SURVEY 8d); peak = %d CU x 64 lanes/clk "
-                 "x %.1f GHz" % (OPS_PER_UNIT_WINDOWED, CUS, CLOCK_HZ / 1e9),
-        "kernel_ms": kernel_ms,
-        "hbm_GBps_algorithmic": 3.0 * W * H / (kernel_ms * 1e-3) / 1e9,
-    }
+    counters = load_counters()
+    roof = valu_roofline(counters, "disp_band_9x9_sad_d256_2880x1988", units, OPS_PER_UNIT_WINDOWED, kernel_ms,
+                         "disp_band_kernel<4,false>: disparity scan, %dx%d SAD, D=%d" % (WIN, WIN, D))
+    c = counters.get("disp_band_9x9_sad_d256_2880x1988", {})
+    # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
+    # command (null when profiles/kernel_counters.json has no entry)
+    roof["traffic"] = (c["fetch_bytes"] + c["write_bytes"]) if "fetch_bytes" in c and "write_bytes" in c else None
+    roof["traffic_source"] = c.get("source")
+    roof["algorithmic_bytes"] = 3.0 * W * H
+    roof["hbm_GBps_algorithmic"] = 3.0 * W * H / (kernel_ms * 1e-3) / 1e9
+    out["roofline"] = roof
 
     # ---- secondary kernels (outside the timed region) ------------------------
     extra = {}
     single = world == 1 and not args.no_extra
     if single:
         ks, kw = max(3, min(25, args.steps // 4)), 1
-        # reference mode: 1x1 window, whole-row search (bit-exact vs the reference)
+        # reference mode: 1x1 window, whole-row search (bit-exact vs the reference).  The kernel
+        # spends one v_sad_u32 per candidate and one v_min3_u32 per two: 1.5 lane-ops per unit is
+        # the model of what it executes (SURVEY's 3-op model would credit it with more than it does)
         ms = event_time_ms(torch, lambda: ctx.disparity_dev(d_l, d_r, d_o, win=1, max_disp=0), ks, kw)
         u = W * W * H
         extra["disparity_reference_mode"] = {
             "workload": "%dx%d, 1x1 window, whole-row search (ComputeDepthImage as written)" % (W, H),
             "ms": ms, "Mpix_disp_per_s": u / (ms * 1e-3) / 1e6,
-            "roofline": {"bound": "valu", "achieved": u * OPS_PER_UNIT_WIN1 / (ms * 1e-3) / 1e12,
-                         "peak": VALU_LANEOPS / 1e12, "unit": "Tlane-op/s",
-                         "frac": u * OPS_PER_UNIT_WIN1 / (ms * 1e-3) / VALU_LANEOPS},
+            "roofline": valu_roofline(counters, "disp_ref_2880x1988", u, 1.5, ms, "disp_ref_kernel"),
         }
         ms = event_time_ms(torch, lambda: ctx.disparity_dev(d_l, d_r, d_o, win=1, max_disp=D), ks, kw)
         extra["disparity_win1_d256"] = {
             "workload": "%dx%d, 1x1 window, %d disparities" % (W, H, D),
             "ms": ms, "Mpix_disp_per_s": units / (ms * 1e-3) / 1e6,
-            "roofline": {"bound": "valu", "achieved": units * OPS_PER_UNIT_WIN1 / (ms * 1e-3) / 1e12,
-                         "peak": VALU_LANEOPS / 1e12, "unit": "Tlane-op/s",
-                         "frac": units * OPS_PER_UNIT_WIN1 / (ms * 1e-3) / VALU_LANEOPS},
+            "roofline": valu_roofline(counters, "disp_band_1x1_d256_2880x1988", units, OPS_PER_UNIT_WIN1, ms),
         }
         ms = event_time_ms(torch, lambda: ctx.disparity_dev(d_l, d_r, d_o, win=WIN, max_disp=D,
                                                             cost_mode=api.COST_SSD), ks, kw)
         extra["disparity_ssd_9x9_d256"] = {
             "workload": "%dx%d, %dx%d SSD window, %d disparities (same sliding-sum kernel, squared taps)" % (W, H, WIN, WIN, D),
             "ms": ms, "Mpix_disp_per_s": units / (ms * 1e-3) / 1e6,
-            "roofline": {"bound": "valu", "achieved": units * OPS_PER_UNIT_WINDOWED / (ms * 1e-3) / 1e12,
-                         "peak": VALU_LANEOPS / 1e12, "unit": "Tlane-op/s",
-                         "frac": units * OPS_PER_UNIT_WINDOWED / (ms * 1e-3) / VALU_LANEOPS},
+            "roofline": valu_roofline(counters, "disp_band_9x9_ssd_d256_2880x1988", units, OPS_PER_UNIT_WINDOWED, ms),
         }
-        # larger SAD windows through the same sliding-sum kernel (two halo lanes per side)
-        for wl in (11, 13, 15):
-            ms = event_time_ms(torch, lambda: ctx.disparity_dev(d_l, d_r, d_o, win=wl, max_disp=D), ks, kw)
-            extra["disparity_sad_%dx%d_d256" % (wl, wl)] = {
-                "workload": "%dx%d, %dx%d SAD window, %d disparities" % (W, H, wl, wl, D),
+        # larger windows through the same sliding-sum kernel (two halo lanes per side)
+        for wl, cm, nm in ((11, api.COST_SAD, "sad"), (13, api.COST_SAD, "sad"), (15, api.COST_SAD, "sad"),
+                           (13, api.COST_SSD, "ssd"), (15, api.COST_SSD, "ssd"), (21, api.COST_SAD, "sad")):
+            ms = event_time_ms(torch, lambda: ctx.disparity_dev(d_l, d_r, d_o, win=wl, max_disp=D, cost_mode=cm), 3, 1)
+            extra["disparity_%s_%dx%d_d256" % (nm, wl, wl)] = {
+                "workload": "%dx%d, %dx%d %s window, %d disparities" % (W, H, wl, wl, nm.upper(), D),
                 "ms": ms, "Mpix_disp_per_s": units / (ms * 1e-3) / 1e6,
             }
-        # BASELINE config 3: one 4K pair, 512 disparities (two passes, u16 output)
-        w3, h3, D3 = 3840, 2160, 512
-        l3, r3 = synth.rectified_pair(303, h3, w3, D3)
-        t_l3, t_r3 = torch.from_numpy(l3).cuda(), torch.from_numpy(r3).cuda()
-        t_o3 = torch.empty((h3, w3), dtype=torch.int16, device="cuda")
-        ms = event_time_ms(torch, lambda: ctx.disparity_dev(t_l3, t_r3, t_o3, win=WIN, max_disp=D3), ks, kw)
-        u3 = units_evaluated(w3, h3, D3)
-        extra["disparity_config3_4k_d512"] = {
-            "workload": "BASELINE config 3 on one GPU: %dx%d, %dx%d SAD, %d disparities, u16 output" % (w3, h3, WIN, WIN, D3),
-            "ms": ms, "Mpix_disp_per_s": u3 / (ms * 1e-3) / 1e6,
-            "roofline": {"bound": "valu", "achieved": u3 * OPS_PER_UNIT_WINDOWED / (ms * 1e-3) / 1e12,
-                         "peak": VALU_LANEOPS / 1e12, "unit": "Tlane-op/s",
-                         "frac": u3 * OPS_PER_UNIT_WINDOWED / (ms * 1e-3) / VALU_LANEOPS},
-        }
-        del t_l3, t_r3, t_o3
-        # BASELINE config 4: batch of 1024 1080p pairs, 192 disparities, one batched launch
-        w4, h4, D4, n4 = 1920, 1080, 192, 1024
-        p4 = [synth.rectified_pair(400 + k, h4, w4, D4) for k in range(4)]
-        t_l4 = torch.from_numpy(np.stack([p[0] for p in p4])).cuda().repeat(n4 // 4, 1, 1)
-        t_r4 = torch.from_numpy(np.stack([p[1] for p in p4])).cuda().repeat(n4 // 4, 1, 1)
-        t_o4 = torch.empty_like(t_l4)
-        ms = event_time_ms(torch, lambda: ctx.disparity_dev(t_l4, t_r4, t_o4, win=WIN, max_disp=D4), 2, 1)
-        u4 = units_evaluated(w4, h4, D4) * n4
-        extra["disparity_config4_batch1024"] = {
-            "workload": "BASELINE config 4 on one GPU: %d x %dx%d pairs (4 distinct, repeated), %dx%d SAD, "
-                        "%d disparities, one batched launch" % (n4, w4, h4, WIN, WIN, D4),
-            "ms": ms, "pairs_per_s": n4 / (ms * 1e-3), "Mpix_disp_per_s": u4 / (ms * 1e-3) / 1e6,
-            "roofline": {"bound": "valu", "achieved": u4 * OPS_PER_UNIT_WINDOWED / (ms * 1e-3) / 1e12,
-                         "peak": VALU_LANEOPS / 1e12, "unit": "Tlane-op/s",
-                         "frac": u4 * OPS_PER_UNIT_WINDOWED / (ms * 1e-3) / VALU_LANEOPS},
-        }
-        del t_l4, t_r4, t_o4
         # rectification warp: batch of 8 x 1080p
         nimg, rh, rw = 8, 1080, 1920
         src_np = np.stack([synth.texture(70 + k, rh, rw) for k in range(2)])
@@ -259,24 +267,27 @@ def main():
                          for k in range(nimg)])
         ms = event_time_ms(torch, lambda: ctx.rectify_dev(src, dstt, Hinv, api.RECT_DST_IS_ZERO), ks, kw)
         gbs = 2.0 * nimg * rh * rw / (ms * 1e-3) / 1e9
+        rr = valu_roofline(counters, "rectify_8x1080p", float(nimg * rh * rw), 50.0, ms, "rectify_kernel<true>")
+        rr["model"] = ("~50 VALU lane-instructions per destination pixel (exact fp32 op order: two correctly rounded "
+                       "divides, five conversions, four compares); x %d pixels" % (nimg * rh * rw))
+        rr["hbm"] = {"achieved_GBps": gbs, "peak_GBps": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS, "bytes_per_pixel": 2,
+                     "note": "algorithmic traffic only; the kernel is bound by VALU issue, not by HBM"}
         extra["rectify"] = {
             "workload": "%d x %dx%d u8, K R K^-1 homographies, zero-initialised destination" % (nimg, rw, rh),
-            "ms": ms, "Mpix_per_s": nimg * rh * rw / (ms * 1e-3) / 1e6,
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "bytes_per_pixel": 2,
-                         "note": "exact fp32 op order incl. two correctly rounded divides per pixel: the kernel "
-                                 "is VALU-issue bound (~50 instructions/pixel), not HBM bound"},
+            "ms": ms, "Mpix_per_s": nimg * rh * rw / (ms * 1e-3) / 1e6, "roofline": rr,
         }
         # FAST-12 corner detection on the left image of the headline pair
         xy = torch.empty((W * H // 4, 2), dtype=torch.float32, device="cuda")
         cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
         ms = event_time_ms(torch, lambda: ctx.fast_detect_dev(d_l, xy, cnt, api.FAST_THRESHOLD), ks, kw)
         gbs = 1.0 * W * H / (ms * 1e-3) / 1e9
+        fr = valu_roofline(counters, "fast12_2880x1988", float(W * H), 107.0, ms, "fast_flags_kernel + fast_scatter_kernel")
+        fr["model"] = "~107 VALU lane-instructions per pixel (two 16-bit ring masks, run-of-12 test); x %d pixels" % (W * H)
+        fr["hbm"] = {"achieved_GBps": gbs, "peak_GBps": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS, "bytes_per_pixel": 1,
+                     "note": "algorithmic traffic only; the kernel is bound by VALU issue, not by HBM"}
         extra["fast12"] = {
             "workload": "%dx%d u8, threshold %d, corners compacted in raster order" % (W, H, api.FAST_THRESHOLD),
-            "ms": ms, "Mpix_per_s": W * H / (ms * 1e-3) / 1e6, "corners": int(cnt.item()),
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "bytes_per_pixel": 1},
+            "ms": ms, "Mpix_per_s": W * H / (ms * 1e-3) / 1e6, "corners": int(cnt.item()), "roofline": fr,
         }
         # Shi-Tomasi scoring + O(n^2) non-maximum suppression + score ordering of those corners
         ncorn = int(cnt.item())
@@ -334,6 +345,136 @@ def main():
             "best_inliers": int(r_inl.max().item()),
             "note": "includes the host-side record preparation and upload of each call",
         }
+        ev = float(rh_) * rn
+        ck = counters.get("ransac_error_200x200k")
+        if ck and ck.get("valu_insts") and ck.get("kernel_ms"):
+            rate = ck["valu_insts"] / (ck["kernel_ms"] * 1e-3)
+            extra["ransac_score"]["roofline"] = {
+                "bound": "valu", "kernel": "ransac_error_kernel", "kernel_ms": ck["kernel_ms"],
+                "issue": {"valu_wave_instr_per_launch": ck["valu_insts"], "wave_instr_per_64_units": ck["valu_insts"] / (ev / 64),
+                          "achieved_Ginstr_per_s": rate / 1e9, "ceiling_Ginstr_per_s": ISSUE_CEILING_WAVE_INSTR / 1e9,
+                          "frac": rate / ISSUE_CEILING_WAVE_INSTR,
+                          "source": "profiles/kernel_counters.json (%s): instruction count AND kernel time from the "
+                                    "profile, not from this run" % ck.get("source", "?")}}
+
+    # ---- north_star's multi-GPU workloads: run at every N ------------------------------
+    def timed(fn, steps, warm=1):
+        """Wall time per call of fn in ms, barrier + synchronize on both sides, max over ranks."""
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el / steps * 1e3
+
+    backend = dist.get_backend() if world > 1 else "none (one process)"
+    # gloo (the shared-GPU rehearsal) moves CPU tensors only
+    to_wire = (lambda t: t.cpu()) if (world > 1 and share) else (lambda t: t)
+    if not args.no_extra:
+        from stereo_amd import dist as sdist
+        # BASELINE config 3: one 4K pair, 512 disparities (two passes, u16 output), row bands + halo
+        w3, h3, D3 = 3840, 2160, 512
+        l3, r3 = synth.rectified_pair(303, h3, w3, D3)
+        t_l3, t_r3 = torch.from_numpy(l3).cuda(), torch.from_numpy(r3).cuda()
+        row0, rows, b0, bh = sdist.row_band(h3, rank, world, WIN // 2)
+        counts3 = [sdist.row_band(h3, r_, world, WIN // 2)[1] for r_ in range(world)]
+        band_out = torch.zeros((rows, w3), dtype=torch.int16, device="cuda")
+        gathered = [None]
+
+        def band_step():
+            if rows > 0:
+                ctx.disparity_rowband_dev(t_l3[b0:b0 + bh], t_r3[b0:b0 + bh], b0, h3, row0, rows, band_out,
+                                          win=WIN, max_disp=D3)
+
+        def band_gather_step():
+            band_step()
+            torch.cuda.current_stream().synchronize()
+            g = sdist.gather_rows(to_wire(band_out), counts3, 0) if world > 1 else band_out
+            gathered[0] = g
+
+        ms_c = timed(band_step, 10)
+        ms_g = timed(band_gather_step, 10)
+        u3 = units_evaluated(w3, h3, D3)
+        leg = {
+            "workload": "BASELINE config 3: one %dx%d pair, %dx%d SAD, %d disparities, u16 map; %d row band(s) with "
+                        "%d halo rows read from each rank's own copy, bands gathered to rank 0"
+                        % (w3, h3, WIN, WIN, D3, world, WIN // 2),
+            "n_ranks": world, "backend": backend, "scaling": "strong",
+            "ms_compute": ms_c, "ms_with_gather": ms_g, "bytes_gathered": int((h3 - counts3[0]) * w3 * 2),
+            "Mpix_disp_per_s": u3 / (ms_g * 1e-3) / 1e6, "Mpix_disp_per_s_compute_only": u3 / (ms_c * 1e-3) / 1e6,
+        }
+        if rank == 0:
+            ref3 = torch.zeros((h3, w3), dtype=torch.int16, device="cuda")
+            ctx.disparity_dev(t_l3, t_r3, ref3, win=WIN, max_disp=D3)
+            torch.cuda.synchronize()
+            leg["gathered_equals_single_gpu_map"] = bool(torch.equal(gathered[0].to(ref3.device), ref3))
+            if world == 1:
+                leg["roofline"] = valu_roofline(counters, "disp_band_9x9_sad_d512_3840x2160", u3, OPS_PER_UNIT_WINDOWED, ms_c)
+            extra["disparity_config3_4k_d512"] = leg
+            del ref3
+        del t_l3, t_r3, band_out
+        gathered[0] = None
+
+        # BASELINE config 4: 1024 1080p pairs, 192 disparities, 1024 / N pairs per rank
+        w4, h4, D4, n4, distinct = 1920, 1080, 192, 1024, 4
+        p4 = [synth.rectified_pair(400 + k, h4, w4, D4) for k in range(distinct)]
+        lo4, hi4 = sdist.shard_range(n4, rank, world)
+        counts4 = [sdist.shard_range(n4, r_, world)[1] - sdist.shard_range(n4, r_, world)[0] for r_ in range(world)]
+        d_l4 = torch.from_numpy(np.stack([p[0] for p in p4])).cuda()
+        d_r4 = torch.from_numpy(np.stack([p[1] for p in p4])).cuda()
+        sel = torch.arange(lo4, hi4, device="cuda") % distinct      # pair k of the batch is distinct pair k mod 4
+        t_l4, t_r4 = d_l4[sel].contiguous(), d_r4[sel].contiguous()
+        t_o4 = torch.empty_like(t_l4)
+
+        def batch_step():
+            ctx.disparity_dev(t_l4, t_r4, t_o4, win=WIN, max_disp=D4)
+
+        def batch_gather_step():
+            batch_step()
+            torch.cuda.current_stream().synchronize()
+            gathered[0] = sdist.gather_rows(to_wire(t_o4), counts4, 0) if world > 1 else t_o4
+
+        ms_c = timed(batch_step, 2)
+        ms_g = timed(batch_gather_step, 2)
+        u4 = units_evaluated(w4, h4, D4) * n4
+        leg = {
+            "workload": "BASELINE config 4: %d x %dx%d pairs (%d distinct, repeated), %dx%d SAD, %d disparities; "
+                        "%d pairs per rank in one batched launch, maps gathered to rank 0"
+                        % (n4, w4, h4, distinct, WIN, WIN, D4, hi4 - lo4),
+            "n_ranks": world, "backend": backend, "scaling": "strong",
+            "ms_compute": ms_c, "ms_with_gather": ms_g, "bytes_gathered": int((n4 - counts4[0]) * w4 * h4),
+            "pairs_per_s": n4 / (ms_c * 1e-3), "pairs_per_s_with_gather": n4 / (ms_g * 1e-3),
+            "Mpix_disp_per_s": u4 / (ms_c * 1e-3) / 1e6,
+        }
+        if rank == 0:
+            single4 = torch.empty_like(d_l4)
+            for k in range(distinct):
+                ctx.disparity_dev(d_l4[k], d_r4[k], single4[k], win=WIN, max_disp=D4)
+            torch.cuda.synchronize()
+            g = gathered[0].to(single4.device)
+            leg["gathered_equals_single_pair_maps"] = bool(
+                (g.view(n4 // distinct, distinct, h4, w4) == single4.unsqueeze(0)).all().item())
+            if world == 1:
+                leg["roofline"] = valu_roofline(counters, "disp_band_9x9_sad_d192_1024x1080p", u4, OPS_PER_UNIT_WINDOWED, ms_c)
+            extra["disparity_config4_batch1024"] = leg
+            del single4, g
+        gathered[0] = None
+        del t_l4, t_r4, t_o4
+        torch.cuda.empty_cache()
+
     if not args.no_extra:
         # descriptor matching (BASELINE config 5).  With N > 1 ranks list1's queries are sharded
         # (list2 replicated, no data-path collective): strong scaling of the one 200k x 200k job.
@@ -354,26 +495,32 @@ def main():
             ctx.match_dev(td1, ts1, td2, ts2, 1000.0, oc, os_, om, od, ot)
 
         msteps = 10
-        mstep()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(msteps):
+        ms = timed(mstep, msteps)
+        counts_m = [shard_range(n, r_, world)[1] - shard_range(n, r_, world)[0] for r_ in range(world)]
+        mg = [None]
+
+        def mstep_gather():
             mstep()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        mel = time.perf_counter() - t0
+            torch.cuda.current_stream().synchronize()
+            if world > 1:   # five small per-query arrays, in list1 order (the order the reference emits pairs in)
+                mg[0] = [sdist.gather_rows(to_wire(t_), counts_m, 0) for t_ in (oc, os_, om, od, ot)]
+            else:
+                mg[0] = [oc, os_, om, od, ot]
+
+        ms_g = timed(mstep_gather, 3)
         acc = torch.tensor([float((ot == 3).sum().item())], device=red_dev, dtype=torch.float64)
         if world > 1:
-            t = torch.tensor([mel], device=red_dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(acc)
-            mel = float(t.item())
-        ms = mel / msteps * 1e3
+        same_m = None
+        if rank == 0 and world > 1:
+            # the single-GPU result of the whole job, on rank 0, against the gathered one
+            fd1, fs1 = torch.from_numpy(d1).cuda(), torch.from_numpy(s1).cuda()
+            fo = [torch.empty(n, dtype=t_.dtype, device="cuda") for t_ in (oc, os_, om, od, ot)]
+            ctx.match_dev(fd1, fs1, td2, ts2, 1000.0, *fo)
+            torch.cuda.synchronize()
+            same_m = all(bool(torch.equal(g_.to("cuda").view(torch.uint8), f_.view(torch.uint8)))
+                         for g_, f_ in zip(mg[0], fo))
+            del fd1, fs1, fo
         flops = 2.0 * n * n * 128
         # the prefilter takes each fp32 dot product as ONE bf16 MFMA product (hi.hi) under a rigorous
         # error bound; the exact replay restores bit-exact results
@@ -381,10 +528,12 @@ def main():
         extra["match"] = {
             "workload": "BASELINE config 5: %d x %d 128-d fp32 SIFT-like descriptors, bf16 MFMA prefilter "
                         "+ exact replay (bit-exact indices); list1 sharded over %d GPU(s)" % (n, n, world),
-            "n_gpus": world, "scaling": "strong",
+            "n_gpus": world, "n_ranks": world, "backend": backend, "scaling": "strong",
             "ms": ms, "matched_descriptors_per_s": n / (ms * 1e-3),
             "pair_evaluations_per_s": float(n) * n / (ms * 1e-3),
             "accepted": int(acc.item()),
+            "ms_with_gather": ms_g, "bytes_gathered": int((n - counts_m[0]) * 17),
+            "gathered_equals_single_gpu_result": same_m,
             "roofline": {"bound": "mfma", "achieved": mfma_flops / (ms * 1e-3) / 1e12 / world,
                          "peak": MFMA_BF16_TFLOPS,
                          "unit": "TFLOP/s per GPU",

@@ -352,7 +352,9 @@ class Context:
               "stx_ransac_score_dev")
 
     # -- D ------------------------------------------------------------------
-    def disparity(self, img0, img1, win=1, max_disp=0, cost_mode=COST_SAD, out_dtype=np.uint8):
+    def disparity(self, img0, img1, win=1, max_disp=0, cost_mode=COST_SAD, out_dtype=np.uint8, out=None):
+        """out: optional C-contiguous [H,W] array of out_dtype to write into (a caller in a loop
+        reuses it; a fresh numpy array costs a page fault per 4 KiB on first touch)."""
         _check_image(img0, "img0")
         _check_image(img1, "img1")
         if img0.shape != img1.shape:
@@ -362,7 +364,10 @@ class Context:
             img0 = np.ascontiguousarray(img0)
         h, w = img0.shape
         out_dtype = np.dtype(out_dtype)
-        out = np.zeros((h, w), out_dtype)
+        if out is None:
+            out = np.zeros((h, w), out_dtype)
+        elif out.shape != (h, w) or out.dtype != out_dtype or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous %s array of shape %s" % (out_dtype, (h, w)))
         stride = img0.strides[0] if h > 1 else max(w, 1)
         fn = {1: self._lib.stx_disparity_u8, 2: self._lib.stx_disparity_u16}[out_dtype.itemsize]
         check(fn(self._h, _ptr(img0), _ptr(img1), w, h, stride, int(win), int(max_disp),

@@ -64,11 +64,17 @@ __device__ __forceinline__ f32x2 divide_pair(f32x2 n, float d)
 //   wx2 = t - x1 is exact in fp32 (= fract(t)) and wx1 = x2 - t is the rounding of the
 //   real number 1 - wx2, i.e. the fp32 operation 1.0f - wx2.
 // (uchar) of the interpolated values (all in [0, 256)) is truncation.
+// Up to two inverse homographies travel as kernel arguments (hinv == nullptr): one image, or
+// the pair of main.cpp:362-369, needs no upload at all.
+struct RectHinv {
+    float h[18];
+};
+
 template <bool ZERO_FILL>
 __global__ __launch_bounds__(RECT_THREADS) void rectify_kernel(
     const uint8_t *__restrict__ src, int src_w, int src_h, unsigned src_stride,
     size_t src_image_stride, uint8_t *__restrict__ dst, int dst_w, int dst_h, size_t dst_stride,
-    size_t dst_image_stride, const float *__restrict__ hinv, int dst_y0)
+    size_t dst_image_stride, const float *__restrict__ hinv, RectHinv hk, int dst_y0)
 {
     const int img = blockIdx.z;
     const int y = blockIdx.y;  // row of the band held at dst; image row dst_y0 + y
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(RECT_THREADS) void rectify_kernel(
     if (x0 >= dst_w) return;
     float hv[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) hv[i] = hinv[img * 9 + i];
+    for (int i = 0; i < 9; ++i) hv[i] = hinv ? hinv[img * 9 + i] : hk.h[(img & 1) * 9 + i];
     const uint8_t *s = src + (size_t)img * src_image_stride;
     // buffer descriptor over this source image: taps are fetched with a 32-bit byte offset in
     // a VGPR and the row pitch as the scalar offset, no 64-bit address arithmetic per tap
@@ -156,21 +162,29 @@ __global__ __launch_bounds__(RECT_THREADS) void rectify_kernel(
 int stx_launch_rectify(stx_ctx *ctx, const uint8_t *d_src, int src_w, int src_h,
                        size_t src_stride, size_t src_image_stride, uint8_t *d_dst, int dst_w,
                        int dst_h, size_t dst_stride, size_t dst_image_stride,
-                       const float *d_hinv, int n_images, int flags, int dst_y0)
+                       const float *d_hinv, int n_images, int flags, int dst_y0, const float *host_hinv)
 {
     if (dst_w <= 0 || dst_h <= 0 || n_images <= 0) return STX_OK;
     if (dst_h > 65535 || n_images > 65535) return STX_ERR_TOO_LARGE;
     // tap offsets are 32-bit: one source image must stay below 4 GiB
     if (src_h > 0 && (unsigned long long)src_stride * (unsigned long long)src_h > 0xFFFFFFFFull)
         return STX_ERR_TOO_LARGE;
+    RectHinv hk = {};
+    if (host_hinv) {
+        if (n_images > 2) return STX_ERR_INVALID_ARG;
+        for (int i = 0; i < 9 * n_images; ++i) hk.h[i] = host_hinv[i];
+        d_hinv = nullptr;
+    } else if (!d_hinv) {
+        return STX_ERR_INVALID_ARG;
+    }
     dim3 grid((dst_w + RECT_THREADS * RECT_PX - 1) / (RECT_THREADS * RECT_PX), dst_h, n_images);
     if (flags == STX_RECT_DST_IS_ZERO)
         hipLaunchKernelGGL(rectify_kernel<true>, grid, dim3(RECT_THREADS), 0, ctx->stream, d_src, src_w,
                            src_h, (unsigned)src_stride, src_image_stride, d_dst, dst_w, dst_h, dst_stride,
-                           dst_image_stride, d_hinv, dst_y0);
+                           dst_image_stride, d_hinv, hk, dst_y0);
     else
         hipLaunchKernelGGL(rectify_kernel<false>, grid, dim3(RECT_THREADS), 0, ctx->stream, d_src, src_w,
                            src_h, (unsigned)src_stride, src_image_stride, d_dst, dst_w, dst_h, dst_stride,
-                           dst_image_stride, d_hinv, dst_y0);
+                           dst_image_stride, d_hinv, hk, dst_y0);
     return (int)hipGetLastError();
 }

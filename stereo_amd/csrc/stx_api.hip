@@ -306,6 +306,9 @@ extern "C" int stx_rectify_u8_dev(stx_ctx *ctx, const uint8_t *d_src, int src_w,
     if (rc) return rc;
     STX_ENTER(ctx);
     if (n_images == 0 || dst_w == 0 || dst_h == 0) return STX_OK;
+    if (n_images <= 2)  // the homographies ride in the kernel arguments: nothing to upload
+        return stx_launch_rectify(ctx, d_src, src_w, src_h, src_stride, src_image_stride, d_dst, dst_w, dst_h,
+                                  dst_stride, dst_image_stride, nullptr, n_images, flags, 0, Hinv);
     int err;
     float *d_hinv = (float *)stx_workspace(ctx, STX_SLOT_HINV, sizeof(float) * 9 * (size_t)n_images, &err);
     if (!d_hinv) return err;
@@ -330,12 +333,8 @@ extern "C" int stx_rectify_rowband_u8_dev(stx_ctx *ctx, const uint8_t *d_src, in
     if ((long long)dst_row0 + dst_rows > (1ll << 24)) return STX_ERR_TOO_LARGE;  // (float)y exact
     STX_ENTER(ctx);
     if (dst_w == 0 || dst_rows == 0) return STX_OK;
-    int err;
-    float *d_hinv = (float *)stx_workspace(ctx, STX_SLOT_HINV, sizeof(float) * 9, &err);
-    if (!d_hinv) return err;
-    STX_HIP(hipMemcpyAsync(d_hinv, Hinv, sizeof(float) * 9, hipMemcpyHostToDevice, ctx->stream));
-    return stx_launch_rectify(ctx, d_src, src_w, src_h, src_stride, 0, d_dst, dst_w, dst_rows,
-                              dst_stride, 0, d_hinv, 1, flags, dst_row0);
+    return stx_launch_rectify(ctx, d_src, src_w, src_h, src_stride, 0, d_dst, dst_w, dst_rows, dst_stride, 0,
+                              nullptr, 1, flags, dst_row0, Hinv);
 }
 
 extern "C" int stx_rectify_u8(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h,

@@ -132,7 +132,8 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
 int stx_launch_rectify(stx_ctx *ctx, const uint8_t *d_src, int src_w, int src_h,
                        size_t src_stride, size_t src_image_stride, uint8_t *d_dst,
                        int dst_w, int dst_h, size_t dst_stride, size_t dst_image_stride,
-                       const float *d_hinv, int n_images, int flags, int dst_y0 = 0);
+                       const float *d_hinv, int n_images, int flags, int dst_y0 = 0,
+                       const float *host_hinv = nullptr);  // host_hinv (n_images <= 2): passed as kernel arguments
 
 int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, int n1,
                      const float *d_desc2, const float *d_score2, int n2,

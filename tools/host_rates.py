@@ -21,6 +21,7 @@ l, r = synth.rectified_pair(2024, H, W, D)
 src = synth.texture(3, 1080, 1920)
 Hinv = ctx.invert_homography(synth.homography(3, 1920, 1080))
 dst = np.zeros_like(src)
+dout = np.zeros_like(l)
 n = 32768
 d1, s1, d2, s2 = synth.descriptor_sets(42, n, n)
 pairs = [synth.rectified_pair(400 + k, 1080, 1920, 192) for k in range(4)]
@@ -38,8 +39,8 @@ for name, st in settings:
     else:
         ctx.set_host_pipeline(True, st[0], st[1])
     row = []
-    row.append(best(lambda: ctx.disparity(l, r, win=9, max_disp=D)))
-    row.append(best(lambda: ctx.disparity(l, r), 7))
+    row.append(best(lambda: ctx.disparity(l, r, win=9, max_disp=D, out=dout)))
+    row.append(best(lambda: ctx.disparity(l, r, out=dout), 7))
     row.append(best(lambda: ctx.rectify(src, dst, Hinv)))
     row.append(best(lambda: ctx.rectify(src, dst, Hinv, stereo_amd.api.RECT_DST_IS_ZERO)))
     row.append(best(lambda: ctx.rectify_disparity(l, r, Hinv, Hinv, win=9, max_disp=D), 7))
@@ -48,4 +49,4 @@ for name, st in settings:
 ctx.set_host_pipeline(True, 0, 0)
 b, m = best(lambda: mc.disparity_batch(ba, bb, win=9, max_disp=192), 5)
 print("stx_disparity_batch_u8, 32 x 1080p pairs, D=192, 1 device: best %.2f ms median %.2f ms = %.0f pairs/s" % (b, m, 32 / m * 1e3))
-print("(best / median of the calls; numpy output allocation included)")
+print("(best / median of the calls; outputs written into reused arrays except for the fused call and matching)")
