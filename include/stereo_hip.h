@@ -68,7 +68,7 @@ extern "C" {
 #define STX_MATCH_MFMA_BF16X1 4 /* same with one bf16 MFMA product and a wider (still rigorous) bound */
 
 /* disparity kernel selector (stx_set_disparity_algo) */
-#define STX_DISP_AUTO 0       /* sliding-sum kernel where it applies (SAD win <= 15, SSD win <= 11), else tap-by-tap */
+#define STX_DISP_AUTO 0       /* register sliding-sum kernel (win <= 15), LDS column-sum kernel (win 17..31) */
 #define STX_DISP_BRUTEFORCE 1 /* tap-by-tap kernel for every D1-ext call */
 
 typedef struct stx_ctx stx_ctx;

@@ -398,12 +398,21 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     constexpr unsigned PK_MASKED = PKW ? 0xFFFF0000u : BAND_MASKED;
     static_assert(!PK || PKW || (PK_PAST > 255u * WIN && WIN * (PK_PAST + 255u * WIN) < 65536u), "half-word costs");
     static_assert(!PKW || 255u * WIN * WIN < 65535u, "half-word costs");
-    static_assert(!SSD || (unsigned long long)WIN * WIN * 65025ull * 256ull < (1ull << 31), "SSD key width");
+    // SSD 13x13 and 15x15 (SSDW): a window cost needs 24 bits, so cost << 8 | code fills the whole
+    // key and bit 31 cannot mark an invalid candidate.  As for PKW the mask word saturates the cost
+    // field (0xFFFFFF00, OR-ed in: above every valid key, the code bits survive), and a disparity
+    // past D gets the same word from a wave-uniform constant folded into the same OR.
+    constexpr bool SSDW = SSD && R > 5;
+    constexpr unsigned SSDW_MASKED = 0xFFFFFF00u;
+    static_assert(!SSD || SSDW || (unsigned long long)WIN * WIN * 65025ull * 256ull < (1ull << 31), "SSD key width");
+    static_assert(!SSDW || (unsigned long long)WIN * WIN * 65025ull * 256ull + 255ull < (unsigned long long)SSDW_MASKED,
+                  "wide SSD key width");
     constexpr unsigned SH = PK ? 16u : SSD ? 8u : BAND_SH;  // key = cost << SH | code
     constexpr unsigned PSH = PK ? 0u : SSD ? 4u : BAND_SH;  // pixel pre-shift in the ring
     constexpr unsigned LOW = (1u << SH) - 1;
     constexpr unsigned PAST_D = SSD ? BAND_MASKED : BAND_PAST_D;
-    constexpr unsigned INIT = PK ? (((unsigned)(WIN * WIN * 255 + 1) << 16) - 1u) : SSD ? 0x7FFFFFFFu : BAND_INIT;
+    constexpr unsigned INIT = PK ? (((unsigned)(WIN * WIN * 255 + 1) << 16) - 1u)
+                                 : SSDW ? SSDW_MASKED : SSD ? 0x7FFFFFFFu : BAND_INIT;
     constexpr int HL = (R + 3) / 4;  // halo lanes on each side of the tile
     constexpr int TILE_OUT = BAND_COLS - 8 * HL;
     constexpr int RING = band_ring(WIN);
@@ -481,7 +490,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
             const int i = tid + k * (int)blockDim.x;
             if (i < rw) {
                 Rrow[slot * rw + i] = fill_r[k] << PSH;
-                Mrow[slot * rw + i] = fill_r[k] ? 0u : (PK ? PK_MASKED : BAND_MASKED);
+                Mrow[slot * rw + i] = fill_r[k] ? 0u : (PK ? PK_MASKED : SSDW ? SSDW_MASKED : BAND_MASKED);
             }
         }
     };
@@ -509,7 +518,8 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
         for (int c = 0; c < 4; ++c) carrier[c] = ((x0 + 4 * lane + c + 1024 * WIN) % WIN) == 0;
 #pragma unroll
         for (int dd = 0; dd < BAND_ND; ++dd) {
-            const unsigned code = dB + dd < a.D ? LOW - (unsigned)(SSD ? dB + dd - a.dbase : dB + dd) : PAST_D;
+            const unsigned code = dB + dd < a.D ? LOW - (unsigned)(SSD ? dB + dd - a.dbase : dB + dd)
+                                                : SSDW ? 0u : PAST_D;
 #pragma unroll
             for (int c = 0; c < 4; ++c) V[dd][c] = carrier[c] ? code : 0u;
         }
@@ -687,8 +697,9 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
                 } else
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    // mask word: 0 or BAND_MASKED
-                    const unsigned key = SSD ? (cost[c] | mv[16 + c - dd]) : (cost[c] + mv[16 + c - dd]);
+                    // mask word: 0 or BAND_MASKED (SSDW: 0 or the saturating word, and the same for d >= D)
+                    const unsigned key = SSDW ? (cost[c] | mv[16 + c - dd] | (dB + dd < a.D ? 0u : SSDW_MASKED))
+                                         : SSD ? (cost[c] | mv[16 + c - dd]) : (cost[c] + mv[16 + c - dd]);
                     if (dd & 1)
                         m[c] = min3_u32(m[c], pend[c], key);
                     else
@@ -744,6 +755,219 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// D1-ext, windows 17x17 .. 31x31 (SAD and SSD): column-sum kernel.
+//
+// The band kernel above keeps a lane's column sums in registers and reaches its neighbours'
+// with DPP, which stops at two lanes to each side (window radius <= 7).  Larger windows keep
+// the column sums in LDS instead: workgroup = a tile of 64 output columns x a band of rows x up
+// to 256 disparities; colsum[d][i] is the running sum, over the window's rows, of the tap cost
+// at tile column i (64 + 2R of them) for disparity d.  Per image row: the entering and the
+// leaving row update every colsum entry (step 1), then every (column, d) window cost is a
+// sliding sum of 2R+1 neighbouring colsum entries (step 2), one 64-bit LDS atomic min per
+// (column, d) picks the winner -- cost in the upper word, ~d in the lower, so equal costs go to
+// the larger d = the lower x1, the reference's first-wins order.  Work per (pixel, candidate)
+// is independent of the window size, as in the band kernel; it is slower than that kernel (LDS
+// instead of registers) and exists so that no window falls off a cliff.
+// ---------------------------------------------------------------------------
+
+constexpr int CS_TX = 64;       // output columns per tile
+constexpr int CS_XS = 97;       // colsum row stride in words (64 + 2*15 = 94 used; odd: no bank conflicts down a column)
+constexpr int CS_XT = 96;       // staged tile columns
+constexpr int CS_D = 256;       // disparities per pass
+constexpr int CS_THREADS = 1024;  // 16 waves: the 100 KB of column sums allow one workgroup per CU
+
+struct ColsumArgs {
+    const uint8_t *img0;
+    const uint8_t *img1;
+    int w, h;
+    size_t stride, pair_stride;
+    int row0, rows, bh;
+    int r;
+    int D, dbase, nd;   // total disparities, first of this pass, disparities of this pass
+    unsigned *keys;     // best cost per pixel between passes (nullptr if one pass)
+    int first_pass;
+    uint8_t *out;
+    size_t out_stride, out_pair_stride;
+    int out_bytes;
+};
+
+template <bool SSD>
+__global__ __launch_bounds__(CS_THREADS) void disp_colsum_kernel(ColsumArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned cs_lds[];
+    const int nd = a.nd, R = a.r, WIN = 2 * R + 1;
+    const int rseg = CS_XT + nd - 1;                 // img1 columns a tile row needs
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(cs_lds);  // [CS_TX]
+    unsigned *colsum = cs_lds + 2 * CS_TX;           // [nd][CS_XS]
+    unsigned *Le = colsum + nd * CS_XS;              // entering / leaving / centre rows of img0 [CS_XT]
+    unsigned *Ll = Le + CS_XT;
+    unsigned *Lc = Ll + CS_XT;
+    unsigned *Re = Lc + CS_XT;                       // the same of img1 [rseg]
+    unsigned *Rl = Re + rseg;
+    unsigned *Rc = Rl + rseg;
+    constexpr unsigned long long NONE = ~0ull;
+
+    const int tid = threadIdx.x;
+    const size_t pair = blockIdx.z;
+    const uint8_t *i0 = a.img0 + pair * a.pair_stride;
+    const uint8_t *i1 = a.img1 + pair * a.pair_stride;
+    const int w = a.w, h = a.h;
+    const int x0 = (int)blockIdx.x * CS_TX;            // first output column
+    const int yb = a.row0 + (int)blockIdx.y * a.bh;
+    const int yend = min(yb + a.bh, a.row0 + a.rows);
+    const int lbase = x0 - R;                          // image column of tile column 0
+    const int rbase = lbase - a.dbase - (nd - 1);      // image column of Re[0]
+
+    for (int i = tid; i < nd * CS_XS; i += CS_THREADS) colsum[i] = 0;
+    if (tid < CS_TX) best[tid] = NONE;
+
+    auto stage_row = [&](unsigned *L, unsigned *Rr, int yy, bool live) {
+        const bool in = live && yy >= 0 && yy < h;
+        for (int i = tid; i < CS_XT; i += CS_THREADS) {
+            const int x = lbase + i;
+            L[i] = (in && x >= 0 && x < w) ? i0[(size_t)yy * a.stride + x] : 0u;
+        }
+        for (int i = tid; i < rseg; i += CS_THREADS) {
+            const int x = rbase + i;
+            Rr[i] = (in && x >= 0 && x < w) ? i1[(size_t)yy * a.stride + x] : 0u;
+        }
+    };
+
+    const int ys0 = yb - R, ys1 = yend - 1 + R;
+    for (int ys = ys0; ys <= ys1; ++ys) {
+        const int y = ys - R;  // the output row whose window is complete after this step
+        __syncthreads();       // the previous row's readers are done with the row segments
+        stage_row(Le, Re, ys, true);
+        stage_row(Ll, Rl, ys - WIN, ys - WIN >= ys0);  // a row that never entered leaves as zeros
+        if (y >= yb) stage_row(Lc, Rc, y, true);
+        __syncthreads();
+        // ---- step 1: colsum[d][i] += cost(entering row) - cost(leaving row) ----------
+        {
+            const int xl = tid & 31, dg = tid >> 5;
+            for (int i = xl; i < CS_XT; i += 32) {
+                const unsigned le = Le[i], ll = Ll[i];
+                for (int dd = dg; dd < nd; dd += CS_THREADS / 32) {
+                    const int j = i + (nd - 1) - dd;  // img1 column lbase + i - (dbase + dd)
+                    unsigned e = absdiff_add(le, Re[j], 0u), l = absdiff_add(ll, Rl[j], 0u);
+                    if (SSD) {
+                        e *= e;
+                        l *= l;
+                    }
+                    colsum[dd * CS_XS + i] += e - l;
+                }
+            }
+        }
+        __syncthreads();
+        if (y < yb) continue;
+        // ---- step 2: window costs by sliding sums along x, winner per column ----------
+        {
+            const int dl = (tid & 31) + 32 * (tid >> 8), g = (tid >> 5) & 7;   // 8 groups of 8 output columns
+            unsigned long long mine[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mine[k] = NONE;
+            for (int dd = dl; dd < nd; dd += CS_THREADS / 8) {
+                const unsigned *row = colsum + dd * CS_XS + 8 * g;  // window of column 8g: row[0 .. 2R]
+                unsigned sum = 0;
+                for (int i = 0; i <= 2 * R; ++i) sum += row[i];
+                const unsigned code = ~(unsigned)(a.dbase + dd);
+                const unsigned *rc = Rc + 8 * g + R + (nd - 1) - dd;  // img1 centre pixel of column 8g at this d
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (k > 0) sum += row[2 * R + k] - row[k - 1];
+                    // candidate x1 = x - d: inside the image, its centre pixel non-zero (:676), d < D
+                    if (rc[k] != 0) {
+                        const unsigned long long key = ((unsigned long long)sum << 32) | code;
+                        mine[k] = key < mine[k] ? key : mine[k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (mine[k] != NONE) atomicMin(best + 8 * g + k, mine[k]);
+        }
+        __syncthreads();
+        // ---- output row y -----------------------------------------------------------------
+        if (tid < CS_TX) {
+            const unsigned long long key = best[tid];
+            best[tid] = NONE;
+            const int x = x0 + tid;
+            if (x < w) {
+                const bool centre = Lc[tid + R] != 0;       // img0 centre 0: the output stays 0 (:670)
+                bool valid = centre && key != NONE;
+                const unsigned cost = (unsigned)(key >> 32);
+                const size_t pix = (size_t)(y - a.row0) * w + x;
+                unsigned *kp = a.keys ? a.keys + pair * (size_t)a.rows * w + pix : nullptr;
+                bool emit = true;
+                if (kp) {
+                    if (!a.first_pass) {
+                        const unsigned old = *kp;   // best cost so far, ~0 = none
+                        valid = valid && cost <= old;  // a later pass holds larger d: it wins ties
+                        emit = valid;
+                    }
+                    if (a.first_pass || valid) *kp = valid ? cost : ~0u;
+                }
+                if (emit) {
+                    const int v = !centre ? 0 : valid ? (int)~(unsigned)key : x;  // no candidate: xBest stays 0
+                    uint8_t *orow = a.out + pair * a.out_pair_stride + (size_t)(y - a.row0) * a.out_stride;
+                    if (a.out_bytes == 1)
+                        orow[x] = (uint8_t)(v & 0xFF);
+                    else
+                        reinterpret_cast<uint16_t *>(orow)[x] = (uint16_t)(v & 0xFFFF);
+                }
+            }
+        }
+    }
+}
+
+template <bool SSD>
+int launch_colsum(stx_ctx *ctx, ColsumArgs a, int n_pairs, void *keys, size_t keys_bytes)
+{
+    const int xt = (a.w + CS_TX - 1) / CS_TX;
+    const int npass = (a.D + CS_D - 1) / CS_D;
+    const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    // band height: the 2R warm-up rows against an even fill of the CUs (as launch_band)
+    int best_bh = a.rows;
+    double best_t = 1e300;
+    for (int bh = 8; bh <= 1024; bh += 4) {
+        const int bands = (a.rows + bh - 1) / bh;
+        const long wgs = (long)xt * bands * n_pairs;
+        const long rounds = (wgs + cus - 1) / cus;
+        const double t = (double)rounds * (bh + 2 * a.r + 1);
+        if (t < best_t) { best_t = t; best_bh = bh; }
+        if (bh >= a.rows) break;
+    }
+    a.bh = best_bh;
+    const int bands = (a.rows + a.bh - 1) / a.bh;
+    if (bands > 65535 || n_pairs > 65535) return STX_ERR_TOO_LARGE;
+    a.keys = nullptr;
+    if (npass > 1) {
+        const size_t need = sizeof(unsigned) * (size_t)n_pairs * a.rows * a.w;
+        if (keys) {
+            if (need > keys_bytes) return STX_ERR_TOO_LARGE;
+            a.keys = static_cast<unsigned *>(keys);
+        } else {
+            int err;
+            a.keys = (unsigned *)stx_workspace(ctx, STX_SLOT_DISP_KEYS, need, &err);
+            if (!a.keys) return err;
+        }
+    }
+    for (int p = 0; p < npass; ++p) {
+        a.dbase = p * CS_D;
+        a.nd = a.D - a.dbase < CS_D ? a.D - a.dbase : CS_D;
+        a.first_pass = p == 0;
+        const int rseg = CS_XT + a.nd - 1;
+        const size_t lds = sizeof(unsigned long long) * CS_TX +
+                           sizeof(unsigned) * ((size_t)a.nd * CS_XS + 3 * CS_XT + 3 * (size_t)rseg);
+        const int rc = stx_set_lds_attr(ctx, reinterpret_cast<const void *>(disp_colsum_kernel<SSD>), (int)lds);
+        if (rc != STX_OK) return rc;
+        hipLaunchKernelGGL((disp_colsum_kernel<SSD>), dim3(xt, bands, n_pairs), dim3(CS_THREADS), lds, ctx->stream, a);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return STX_OK;
 }
 
 template <int R, bool SSD>
@@ -830,7 +1054,7 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
     const int D = max_disp < w ? max_disp : w;  // candidates beyond column 0 do not exist
     const bool ssd = cost_mode == STX_COST_SSD && r > 0;  // a single tap orders candidates as SAD does
     // (the band kernel addresses an image through 32-bit buffer offsets: one image below 2 GiB)
-    if (r <= (ssd ? 5 : 7) && D <= 4096 && !ctx->force_bruteforce && (unsigned long long)stride * (unsigned)h < (1ull << 31)) {
+    if (r <= 7 && D <= 4096 && !ctx->force_bruteforce && (unsigned long long)stride * (unsigned)h < (1ull << 31)) {
         BandArgs a;
         a.img0 = d_img0; a.img1 = d_img1; a.w = w; a.h = h; a.stride = stride;
         a.pair_stride = pair_stride; a.row0 = row0; a.rows = rows; a.bh = rows; a.D = D;
@@ -842,7 +1066,9 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
             case 2: return launch_band<2, true>(ctx, a, n_pairs, keys, keys_bytes);
             case 3: return launch_band<3, true>(ctx, a, n_pairs, keys, keys_bytes);
             case 4: return launch_band<4, true>(ctx, a, n_pairs, keys, keys_bytes);
-            default: return launch_band<5, true>(ctx, a, n_pairs, keys, keys_bytes);
+            case 5: return launch_band<5, true>(ctx, a, n_pairs, keys, keys_bytes);
+            case 6: return launch_band<6, true>(ctx, a, n_pairs, keys, keys_bytes);
+            default: return launch_band<7, true>(ctx, a, n_pairs, keys, keys_bytes);
             }
         }
         switch (r) {
@@ -855,6 +1081,15 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
         case 6: return launch_band<6, false>(ctx, a, n_pairs, keys, keys_bytes);
         default: return launch_band<7, false>(ctx, a, n_pairs, keys, keys_bytes);
         }
+    }
+    if (r > 7 && r <= 15 && D <= 65536 && !ctx->force_bruteforce) {
+        ColsumArgs c;
+        c.img0 = d_img0; c.img1 = d_img1; c.w = w; c.h = h; c.stride = stride; c.pair_stride = pair_stride;
+        c.row0 = row0; c.rows = rows; c.bh = rows; c.r = r; c.D = D; c.dbase = 0; c.nd = 0; c.keys = nullptr;
+        c.first_pass = 1; c.out = o; c.out_stride = out_stride; c.out_pair_stride = out_pair_stride;
+        c.out_bytes = out_bytes;
+        return cost_mode == STX_COST_SSD ? launch_colsum<true>(ctx, c, n_pairs, keys, keys_bytes)
+                                         : launch_colsum<false>(ctx, c, n_pairs, keys, keys_bytes);
     }
     const size_t lds = (size_t)(EXT_TX + 2 * r) * (EXT_TY + 2 * r) +
                        (size_t)(EXT_TX + 2 * r + D - 1) * (EXT_TY + 2 * r);

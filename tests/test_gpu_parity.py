@@ -112,7 +112,7 @@ def test_disparity_sliding_kernel_tiles_and_passes(ctx, oracle, win, h, w, D):
     assert (got == want).all(), np.argwhere(got != want)[:10]
 
 
-@pytest.mark.parametrize("win", [3, 5, 7, 9, 11])
+@pytest.mark.parametrize("win", [3, 5, 7, 9, 11, 13, 15])
 @pytest.mark.parametrize("h,w,D", [(40, 300, 16), (60, 520, 100), (33, 777, 256), (25, 1100, 300),
                                    (20, 900, 700)])
 def test_disparity_sliding_kernel_ssd(ctx, oracle, win, h, w, D):
@@ -136,10 +136,64 @@ def test_disparity_ssd_extreme_contrast(ctx, oracle):
     b[:, 300:] = 255                      # exact matches (cost 0) far to the right
     # 11x11 (half-word SAD sums up to 255*121, SSD keys up to 65025*121 << 8) and 13x13 SAD as well
     for win, cm in ((9, api.COST_SAD), (9, api.COST_SSD), (11, api.COST_SAD), (11, api.COST_SSD),
-                    (13, api.COST_SAD), (13, api.COST_SSD), (15, api.COST_SAD)):
+                    (13, api.COST_SAD), (13, api.COST_SSD), (15, api.COST_SAD), (15, api.COST_SSD),
+                    (17, api.COST_SAD), (23, api.COST_SSD), (31, api.COST_SAD), (31, api.COST_SSD)):
         want = oracle.disparity_ext(a, b, win, D, cm, np.uint16, sliding=True)
         got = ctx.disparity(a, b, win=win, max_disp=D, cost_mode=cm, out_dtype=np.uint16)
         assert (got == want).all(), (win, cm, np.argwhere(got != want)[:10])
+
+
+@pytest.mark.parametrize("cm", [api.COST_SAD, api.COST_SSD])
+@pytest.mark.parametrize("win", [17, 19, 21, 25, 31])
+@pytest.mark.parametrize("h,w,D", [(40, 300, 16), (90, 200, 100), (50, 777, 256), (36, 700, 300), (1, 65, 5),
+                                   (70, 64, 64), (33, 129, 700)])
+def test_disparity_large_windows_column_sum_kernel(ctx, oracle, win, h, w, D, cm):
+    """Windows 17x17 .. 31x31 (the LDS column-sum kernel): several 64-column tiles and row bands,
+    images smaller than the window, D not a multiple of anything, several 256-disparity passes
+    merged through the per-pixel cost buffer (D = 300, 700), SAD and SSD; against the sliding
+    oracle (itself checked against the tap-by-tap oracle in tests/test_oracle_kat.py) and, for
+    one case per window, against the tap-by-tap GPU kernel."""
+    a, b = _rand_pair(win * 5 + h + w + D + cm, h, w, zero=0.03)
+    dt = np.uint16 if D > 256 else np.uint8
+    want = oracle.disparity_ext(a, b, win, D, cm, dt, sliding=True)
+    got = ctx.disparity(a, b, win=win, max_disp=D, cost_mode=cm, out_dtype=dt)
+    assert (got == want).all(), np.argwhere(got != want)[:10]
+    if (h, w, D) == (40, 300, 16):
+        ctx.set_disparity_algo(api.DISP_BRUTEFORCE)
+        try:
+            brute = ctx.disparity(a, b, win=win, max_disp=D, cost_mode=cm, out_dtype=dt)
+        finally:
+            ctx.set_disparity_algo(api.DISP_AUTO)
+        assert (brute == want).all()
+
+
+def test_disparity_large_window_batch_rowband_and_noalloc(ctx, oracle):
+    """The column-sum kernel behind the batched, row-band and no-allocation entry points."""
+    import torch
+    from stereo_amd.dist import row_band
+    pairs = [_rand_pair(70 + s, 60, 260) for s in range(3)]
+    a = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
+    b = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    win, D = 21, 300
+    want = [oracle.disparity_ext(p[0], p[1], win, D, 1, np.uint16, sliding=True) for p in pairs]
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        out = torch.zeros(a.shape, dtype=torch.int16, device="cuda")
+        ctx.disparity_dev(a, b, out, win=win, max_disp=D, cost_mode=api.COST_SSD)
+        out2 = torch.zeros(a.shape, dtype=torch.int16, device="cuda")
+        ctx.disparity_dev_noalloc(a, b, out2, win=win, max_disp=D, cost_mode=api.COST_SSD)
+        full = torch.zeros((60, 260), dtype=torch.int16, device="cuda")
+        for r in range(3):
+            row0, rows, b0, bh = row_band(60, r, 3, win // 2)
+            ctx.disparity_rowband_dev(a[1, b0:b0 + bh], b[1, b0:b0 + bh], b0, 60, row0, rows,
+                                      full[row0:row0 + rows], win=win, max_disp=D, cost_mode=api.COST_SSD)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_stream(0)
+    for k in range(3):
+        assert (out[k].cpu().numpy().view(np.uint16) == want[k]).all()
+        assert (out2[k].cpu().numpy().view(np.uint16) == want[k]).all()
+    assert (full.cpu().numpy().view(np.uint16) == want[1]).all()
 
 
 @pytest.mark.parametrize("h,w,win,D", [(1, 1, 3, 4), (2, 3, 5, 8), (5, 64, 9, 16), (17, 65, 9, 16),

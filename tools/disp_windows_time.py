@@ -15,12 +15,12 @@ a, b = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
 out = torch.empty((H, W), dtype=torch.uint8, device="cuda")
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 for cm, name in ((api.COST_SAD, "SAD"), (api.COST_SSD, "SSD")):
-    for win in (9, 11, 13, 15):
+    for win in (9, 11, 13, 15, 17, 21, 31):
         for _ in range(2):
             ctx.disparity_dev(a, b, out, win=win, max_disp=D, cost_mode=cm)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 5 if win <= 13 else 2
+        n = 5
         e0.record()
         for _ in range(n):
             ctx.disparity_dev(a, b, out, win=win, max_disp=D, cost_mode=cm)
