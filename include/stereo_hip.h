@@ -142,6 +142,14 @@ int stx_rectify_u8(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h,
                    size_t src_stride, uint8_t *dst, int dst_w, int dst_h,
                    size_t dst_stride, const float Hinv[9], int flags);
 
+/* stx_rectify_u8 that also KEEPS the warped image on the GPU, in resident slot `slot` (0 or 1)
+ * of the context, for stx_disparity_resident_u8: main.cpp:362-380 warps two images and scans
+ * them at once, and what the scan reads is exactly what these two calls wrote.  A slot holds
+ * its image until the next stx_rectify_u8_keep on it (any other call leaves it alone). */
+int stx_rectify_u8_keep(stx_ctx *ctx, int slot, const uint8_t *src, int src_w, int src_h,
+                        size_t src_stride, uint8_t *dst, int dst_w, int dst_h, size_t dst_stride,
+                        const float Hinv[9], int flags);
+
 /* Batched, device-resident form: n_images images, image k at
  * d_src + k*src_image_stride / d_dst + k*dst_image_stride, warped with
  * Hinv[9*k .. 9*k+8] (host array).  Asynchronous. */
@@ -176,6 +184,13 @@ int stx_rectify_rowband_u8_dev(stx_ctx *ctx, const uint8_t *d_src, int src_w, in
 int stx_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int w,
                      int h, size_t stride, int win, int max_disp, int cost_mode,
                      uint8_t *out, size_t out_stride);
+
+/* stx_disparity_u8 over the two resident images left by stx_rectify_u8_keep (img0 = slot
+ * slot_img0, img1 = slot slot_img1; both must hold w x h images, else STX_ERR_INVALID_ARG):
+ * no upload.  The CALLER asserts that its host copies of the two images have not changed since
+ * the warp wrote them -- the library cannot see host writes. */
+int stx_disparity_resident_u8(stx_ctx *ctx, int slot_img0, int slot_img1, int w, int h, int win,
+                              int max_disp, int cost_mode, uint8_t *out, size_t out_stride);
 
 /* uint16 output (value mod 65536) for max_disp > 256; out_stride in bytes. */
 int stx_disparity_u16(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int w,

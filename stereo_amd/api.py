@@ -154,6 +154,29 @@ class Context:
             Hinv.ctypes.data_as(C.POINTER(C.c_float)), int(flags)), "stx_rectify_u8")
         return rectified
 
+    def rectify_keep(self, slot, original, rectified, Hinv, flags=RECT_PRESERVE_DST):
+        """rectify() that also keeps the warped image on the GPU in resident slot 0 or 1."""
+        _check_image(original, "original")
+        _check_image(rectified, "rectified", writable=True)
+        Hinv = np.ascontiguousarray(Hinv, np.float32).reshape(9)
+        check(self._lib.stx_rectify_u8_keep(
+            self._h, int(slot), _ptr(original), original.shape[1], original.shape[0],
+            original.strides[0] if original.shape[0] > 1 else max(original.shape[1], 1),
+            _ptr(rectified), rectified.shape[1], rectified.shape[0],
+            rectified.strides[0] if rectified.shape[0] > 1 else max(rectified.shape[1], 1),
+            Hinv.ctypes.data_as(C.POINTER(C.c_float)), int(flags)), "stx_rectify_u8_keep")
+        return rectified
+
+    def disparity_resident(self, slot_img0, slot_img1, shape, win=1, max_disp=0, cost_mode=COST_SAD, out=None):
+        """disparity() over the two resident images left by rectify_keep (shape = (H, W))."""
+        h, w = int(shape[0]), int(shape[1])
+        if out is None:
+            out = np.zeros((h, w), np.uint8)
+        check(self._lib.stx_disparity_resident_u8(self._h, int(slot_img0), int(slot_img1), w, h, int(win),
+                                                  int(max_disp), int(cost_mode), _ptr(out), max(w, 1)),
+              "stx_disparity_resident_u8")
+        return out
+
     def rectify_dev(self, src, dst, Hinv, flags=RECT_PRESERVE_DST):
         """src: [n,H,W] or [H,W] uint8 device tensor; dst likewise; Hinv: n x 9 host floats."""
         s3 = src if src.dim() == 3 else src.unsqueeze(0)

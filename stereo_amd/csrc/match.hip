@@ -989,13 +989,12 @@ __global__ __launch_bounds__(64) void match_replay_kernel(
     float *__restrict__ min_dist_out, float *__restrict__ second_dist_out, uint8_t *__restrict__ status_out)
 {
     __shared__ int cj_[RP_G][MF_CAP];
-    __shared__ int sj_[RP_G][MF_CAP];
     __shared__ float dist_[RP_G][MF_CAP];
     __shared__ float q_[RP_G][K];
     const int g = threadIdx.x / RP_L;
     const int l = threadIdx.x % RP_L;
     const int i = blockIdx.x * RP_G + g;
-    int *cj = cj_[g], *sj = sj_[g];
+    int *cj = cj_[g];
     float *dist = dist_[g], *q = q_[g];
     // the query's candidates: nsub sub-lists of at most subcap entries (one list for the atomic
     // kernels, one per (segment, half) for the x1 kernel)
@@ -1024,19 +1023,22 @@ __global__ __launch_bounds__(64) void match_replay_kernel(
         for (int k = l; k < K; k += RP_L) q[k] = desc1[(size_t)i * K + k];
     }
     __syncthreads();
-    // rank sort (candidate indices are distinct)
+    // Exact distances of the candidates, in any order.  The reference's scan over ascending j
+    // (Features.cpp:1036-1047) needs no sort to replay: its `closest` is the first index of the
+    // smallest distance and its `second` the first index of the smallest distance among j <
+    // closest -- both are records, hence candidates, and every other candidate is no smaller --
+    // so two lexicographic (distance, index) minima give them.  NaN: list2[0] is taken
+    // unconditionally (:1041, minDist == -1), so a NaN there sticks; any later NaN never
+    // satisfies dist < minDist and counts as +inf.  (list2[0] is always a candidate: a piece
+    // starts with a cold bound that passes its whole first block.)
+    const float inf = __builtin_inff();
+    float bd = inf, d0 = 0.0f;
+    int bj = 0x7FFFFFFF;
+    bool nan0 = false;
 #pragma unroll 1
     for (int p = l; p < count; p += RP_L) {
         const int j = cj[p];
-        int rank = 0;
-#pragma unroll 4
-        for (int o = 0; o < count; ++o) rank += cj[o] < j;
-        sj[rank] = j;
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int p = l; p < count; p += RP_L) {
-        const float4 *b = reinterpret_cast<const float4 *>(desc2 + (size_t)sj[p] * K);
+        const float4 *b = reinterpret_cast<const float4 *>(desc2 + (size_t)j * K);
         float norm = 0.0f;
 #pragma unroll 8
         for (int k4 = 0; k4 < K / 4; ++k4) {  // reference order: k ascending, one accumulator
@@ -1048,25 +1050,58 @@ __global__ __launch_bounds__(64) void match_replay_kernel(
             d = qv.z - bv.z; norm = norm + d * d;
             d = qv.w - bv.w; norm = norm + d * d;
         }
-        dist[p] = sqrtf(norm);
+        const float dt = sqrtf(norm);
+        dist[p] = dt;
+        if (j == 0) { nan0 = dt != dt; d0 = dt; }
+        const float dd = dt == dt ? dt : inf;
+        if (dd < bd || (dd == bd && j < bj)) { bd = dd; bj = j; }
+    }
+    // reduce over the query's RP_L lanes (xor butterflies stay inside the aligned group)
+#pragma unroll
+    for (int m = RP_L / 2; m > 0; m >>= 1) {
+        const float od = __shfl_xor(bd, m);
+        const int oj = __shfl_xor(bj, m);
+        if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+        nan0 |= (bool)__shfl_xor((int)nan0, m);
+        const float o0 = __shfl_xor(d0, m);
+        d0 = (o0 != 0.0f || o0 != o0) ? o0 : d0;  // only the lane that met j == 0 holds a value
     }
     __syncthreads();
-    if (l != 0 || !live) return;
     int closest = -1, second = -1;
     float min_dist = -1.0f, second_dist = -1.0f;
-    if (count > 0) {  // sj[0] is list2[0]: taken unconditionally (minDist == -1, Features.cpp:1041)
-        closest = sj[0];
-        min_dist = dist[0];
+    if (count > 0) {
+        if (nan0) {
+            closest = 0;
+            min_dist = d0;
+        } else {
+            closest = bj;
+            // the true value (bd is it unless every candidate is NaN-or-inf, where +inf is also right
+            // only if list2[0] is +inf: then closest == 0 and dist of j == 0 is what the scan holds)
+            min_dist = bd;
+            float sd = inf;
+            int sj = 0x7FFFFFFF;
 #pragma unroll 1
-        for (int p = 1; p < count; ++p) {
-            if (dist[p] < min_dist) {
-                second = closest;
-                second_dist = min_dist;
-                closest = sj[p];
-                min_dist = dist[p];
+            for (int p = l; p < count; p += RP_L) {
+                const int j = cj[p];
+                if (j < closest) {
+                    const float dt = dist[p];
+                    const float dd = dt == dt ? dt : inf;
+                    if (dd < sd || (dd == sd && j < sj)) { sd = dd; sj = j; }
+                }
+            }
+#pragma unroll
+            for (int m = RP_L / 2; m > 0; m >>= 1) {
+                const float od = __shfl_xor(sd, m);
+                const int oj = __shfl_xor(sj, m);
+                if (od < sd || (od == sd && oj < sj)) { sd = od; sj = oj; }
+            }
+            if (sj != 0x7FFFFFFF) {
+                second = sj;
+                second_dist = sd;
             }
         }
     }
+    if (l != 0 || !live) return;
     if (closest_out) closest_out[i] = closest;
     if (second_out) second_out[i] = second;
     if (min_dist_out) min_dist_out[i] = min_dist;

@@ -352,6 +352,50 @@ extern "C" int stx_rectify_u8(stx_ctx *ctx, const uint8_t *src, int src_w, int s
     return stx_rectify_host(ctx, src, src_w, src_h, src_stride, dst, dst_w, dst_h, dst_stride, Hinv, flags);
 }
 
+static int check_disparity_args(int w, int h, size_t stride, int win, int max_disp, int cost_mode, int out_bytes,
+                                size_t out_stride);
+
+extern "C" int stx_rectify_u8_keep(stx_ctx *ctx, int slot, const uint8_t *src, int src_w, int src_h,
+                                   size_t src_stride, uint8_t *dst, int dst_w, int dst_h, size_t dst_stride,
+                                   const float Hinv[9], int flags)
+{
+    if (!ctx || !Hinv || (slot != 0 && slot != 1)) return STX_ERR_INVALID_ARG;
+    if (flags != STX_RECT_PRESERVE_DST && flags != STX_RECT_DST_IS_ZERO) return STX_ERR_INVALID_ARG;
+    int rc = check_image(src, src_w, src_h, src_stride);
+    if (rc) return rc;
+    rc = check_image(dst, dst_w, dst_h, dst_stride);
+    if (rc) return rc;
+    STX_ENTER(ctx);
+    ctx->res_w[slot] = ctx->res_h[slot] = 0;
+    if (dst_w == 0 || dst_h == 0) return STX_OK;
+    int err;
+    uint8_t *keep = (uint8_t *)stx_workspace(ctx, STX_SLOT_RES0 + slot, (size_t)dst_w * (size_t)dst_h, &err);
+    if (!keep) return err;
+    rc = stx_rectify_host(ctx, src, src_w, src_h, src_stride, dst, dst_w, dst_h, dst_stride, Hinv, flags, keep);
+    if (rc) return rc;
+    ctx->res_w[slot] = dst_w;
+    ctx->res_h[slot] = dst_h;
+    return STX_OK;
+}
+
+extern "C" int stx_disparity_resident_u8(stx_ctx *ctx, int slot_img0, int slot_img1, int w, int h, int win,
+                                         int max_disp, int cost_mode, uint8_t *out, size_t out_stride)
+{
+    if (!ctx || (slot_img0 != 0 && slot_img0 != 1) || (slot_img1 != 0 && slot_img1 != 1)) return STX_ERR_INVALID_ARG;
+    int rc = check_disparity_args(w, h, (size_t)(w > 0 ? w : 0), win, max_disp, cost_mode, 1, out_stride);
+    if (rc) return rc;
+    // both slots must hold an image of exactly this size (stx_rectify_u8_keep)
+    if (ctx->res_w[slot_img0] != w || ctx->res_h[slot_img0] != h || ctx->res_w[slot_img1] != w ||
+        ctx->res_h[slot_img1] != h)
+        return STX_ERR_INVALID_ARG;
+    if (w == 0 || h == 0) return STX_OK;
+    if (!out) return STX_ERR_INVALID_ARG;
+    STX_ENTER(ctx);
+    return stx_disparity_resident_host(ctx, (const uint8_t *)ctx->slot_ptr[STX_SLOT_RES0 + slot_img0],
+                                       (const uint8_t *)ctx->slot_ptr[STX_SLOT_RES0 + slot_img1], w, h, win, max_disp,
+                                       cost_mode, out, out_stride, 1);
+}
+
 // ---------------------------------------------------------------- D (host) --
 
 static int check_disparity_args(int w, int h, size_t stride, int win, int max_disp,

@@ -424,14 +424,14 @@ int stx_disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, i
 // One image through the warp (RectifyImage's loop): the source goes up in chunks, the kernel
 // runs once, destination row bands come back chunk by chunk.
 int stx_rectify_host(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h, size_t src_stride, uint8_t *dst,
-                     int dst_w, int dst_h, size_t dst_stride, const float Hinv[9], int flags)
+                     int dst_w, int dst_h, size_t dst_stride, const float Hinv[9], int flags, uint8_t *d_keep)
 {
     int err;
     const size_t sp = (size_t)(src_w > 0 ? src_w : 1), dp = (size_t)dst_w;
     const size_t sbytes = sp * (size_t)(src_h > 0 ? src_h : 1), dbytes = dp * (size_t)dst_h;
     uint8_t *dsrc = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG0, sbytes, &err);
     if (!dsrc) return err;
-    uint8_t *ddst = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG1, dbytes, &err);
+    uint8_t *ddst = d_keep ? d_keep : (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG1, dbytes, &err);
     if (!ddst) return err;
     const bool have_src = src_w > 0 && src_h > 0;
     const bool preserve = flags == STX_RECT_PRESERVE_DST;
@@ -497,6 +497,53 @@ int stx_rectify_host(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h, siz
     }
     for (int c = 0; c < ncd; ++c) {
         rc = stx_host_download_end(ctx, dst + (size_t)lo[c] * dst_stride, dst_stride, pin_out + (size_t)lo[c] * dp, dp,
+                                   (size_t)cnt[c], ctx->ev_out[c]);
+        if (rc) return rc;
+    }
+    return STX_OK;
+}
+
+// Scan of two images that are already on the device (dense, pitch == w); the map comes back in
+// row-band chunks, each band's download behind its kernel.
+int stx_disparity_resident_host(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_img1, int w, int h, int win,
+                                int max_disp, int cost_mode, void *out, size_t out_stride, int out_bytes)
+{
+    int err;
+    const size_t p = (size_t)w, op = p * (size_t)out_bytes, oimg = op * (size_t)h;
+    uint8_t *o = static_cast<uint8_t *>(out);
+    uint8_t *dout = (uint8_t *)stx_workspace(ctx, STX_SLOT_OUT, oimg, &err);
+    if (!dout) return err;
+    if (!stx_host_pipeline_on(ctx)) {
+        int rc = stx_launch_disparity(ctx, d_img0, d_img1, 1, w, h, p, 0, 0, h, win, max_disp, cost_mode, dout, op, 0,
+                                      out_bytes);
+        if (rc) return rc;
+        if (out_stride == op)
+            STX_HIP(hipMemcpyAsync(o, dout, oimg, hipMemcpyDeviceToHost, ctx->stream));
+        else
+            STX_HIP(hipMemcpy2DAsync(o, out_stride, dout, op, op, h, hipMemcpyDeviceToHost, ctx->stream));
+        STX_HIP(hipStreamSynchronize(ctx->stream));
+        return STX_OK;
+    }
+    int rc = stx_host_prepare(ctx, 0, oimg);
+    if (rc) return rc;
+    rc = fence_copy_streams(ctx);
+    if (rc) return rc;
+    uint8_t *pin_out = (uint8_t *)ctx->pin_ptr[1];
+    const int nc = stx_host_chunks(ctx, oimg, (size_t)(h + 63) / 64);
+    int lo[STX_HOST_MAX_CHUNKS], cnt[STX_HOST_MAX_CHUNKS];
+    for (int c = 0; c < nc; ++c) {
+        lo[c] = (int)((long long)h * c / nc);
+        cnt[c] = (int)((long long)h * (c + 1) / nc) - lo[c];
+        rc = stx_launch_disparity(ctx, d_img0, d_img1, 1, w, h, p, 0, lo[c], cnt[c], win, max_disp, cost_mode,
+                                  dout + (size_t)lo[c] * op, op, 0, out_bytes);
+        if (rc) return rc;
+        STX_HIP(hipEventRecord(ctx->ev_k[c], ctx->stream));
+        rc = stx_host_download_begin(ctx, pin_out + (size_t)lo[c] * op, dout + (size_t)lo[c] * op, (size_t)cnt[c] * op,
+                                     ctx->ev_k[c], ctx->ev_out[c]);
+        if (rc) return rc;
+    }
+    for (int c = 0; c < nc; ++c) {
+        rc = stx_host_download_end(ctx, o + (size_t)lo[c] * out_stride, out_stride, pin_out + (size_t)lo[c] * op, op,
                                    (size_t)cnt[c], ctx->ev_out[c]);
         if (rc) return rc;
     }

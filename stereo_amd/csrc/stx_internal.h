@@ -26,6 +26,8 @@ enum stx_slot {
     STX_SLOT_SCORE_IO,   // host-API staging of the scoring call: gradient images, features, outputs
     STX_SLOT_SIFT_TABLES, // descriptors: atan table + Gaussian kernels (built once per context)
     STX_SLOT_RANSAC,     // hypothesis scoring: records + per-pair errors
+    STX_SLOT_RES0,       // resident image 0 (stx_rectify_u8_keep -> stx_disparity_resident_u8)
+    STX_SLOT_RES1,       // resident image 1
     STX_SLOT_COUNT
 };
 
@@ -44,6 +46,7 @@ struct stx_ctx {
     // (hipGetSymbolAddress at stx_create; disparity.hip), and its size in bytes
     void *disp_scratch;
     size_t disp_scratch_bytes;
+    int res_w[2], res_h[2];  // dimensions of the resident images (0: slot empty)
     // Host-pointer entry points: pinned staging (grow-only), a second stream and events for
     // the chunked upload / compute / download pipeline, worker threads for the host copies.
     void *pin_ptr[2];  // [0] uploads, [1] downloads
@@ -108,8 +111,13 @@ int stx_host_upload_flat(stx_ctx *ctx, void *d_dst, const void *src, size_t byte
 int stx_disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int n_pairs, int w, int h,
                        size_t stride, size_t pair_stride, int row0, int rows, int win, int max_disp,
                        int cost_mode, void *out, size_t out_stride, size_t out_pair_stride, int out_bytes);
+// d_keep: device buffer (dense, dst_w x dst_h) that receives the warped image instead of the
+// staging slot, e.g. a resident-image slot; nullptr = staging slot.
 int stx_rectify_host(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h, size_t src_stride, uint8_t *dst,
-                     int dst_w, int dst_h, size_t dst_stride, const float Hinv[9], int flags);
+                     int dst_w, int dst_h, size_t dst_stride, const float Hinv[9], int flags,
+                     uint8_t *d_keep = nullptr);
+int stx_disparity_resident_host(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_img1, int w, int h, int win,
+                                int max_disp, int cost_mode, void *out, size_t out_stride, int out_bytes);
 
 // disparity.hip: device address and size of this device's static scratch array.
 int stx_disparity_scratch(void **ptr, size_t *bytes);

@@ -28,6 +28,9 @@ struct StereoPair { ImageDescriptor img1, img2; Eigen::Matrix3f F, E; };
 bool FindFundamentalMatrix(const std::vector<std::pair<Feature, Feature> > &matches, Eigen::Matrix3f &F);
 bool DecomposeEssentialMatrix(Eigen::Matrix3f &E, Eigen::Matrix3f &R1, Eigen::Matrix3f &R2, Eigen::Vector3f &t);
 
+// the caller's statement that it does not write to the rectified Mats between RectifyImage and
+// ComputeDepthImage (main.cpp:362-380 does not): the scan then reads the GPU-resident copies
+#define STEREO_DROPIN_REUSE_RECTIFIED
 #include "stereo_dropin.hpp"
 #include "stereo_oracle.h"
 
@@ -286,6 +289,72 @@ int main()
         std::vector<std::pair<Feature, Feature> > few(matches.begin(), matches.begin() + 7);
         if (FindFundamentalMatrixWithRANSAC(few, F, stereo)) ++fails;
         std::printf("RANSAC fails so far: %d (solved %d, inner failures %d, minError %d)\n", fails, solved, failed_inner, minError);
+    }
+    // ---- main.cpp:362-380: RectifyImage x2 -> ComputeDepthImage on the resident copies -----
+    {
+        const int w = 333, h = 120;
+        cv::Mat s0(h, w, 0), s1(h, w, 0);
+        for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+            s0.at<uint8_t>(y, x) = 1 + rnd() % 255;
+            s1.at<uint8_t>(y, x) = 1 + rnd() % 255;
+        }
+        cv::Mat r0 = cv::Mat::zeros(cv::Size(w, h), CV_8U), r1 = cv::Mat::zeros(cv::Size(w, h), CV_8U);
+        const float ha[9] = {0.9996f, -0.0061f, 7.5f, 0.0060f, 1.0001f, -2.25f, 0.9e-5f, -1.0e-6f, 1.0f};
+        const float hb[9] = {1.0003f, 0.0042f, -5.5f, -0.0041f, 0.9998f, 3.75f, -0.7e-5f, 2.0e-6f, 1.0f};
+        Eigen::Matrix3f HA, HB;
+        for (int i = 0; i < 9; ++i) { HA.m[i] = ha[i]; HB.m[i] = hb[i]; }
+        RectifyImage(s0, r0, HA);
+        RectifyImage(s1, r1, HB);
+        cv::Mat depth = ComputeDepthImage(r0, r1);   // both Mats are resident: nothing is uploaded
+        float ia[9], ib[9];
+        oracle_invert3x3(ha, ia);
+        oracle_invert3x3(hb, ib);
+        std::vector<uint8_t> w0((size_t)w * h, 0), w1((size_t)w * h, 0), wd((size_t)w * h, 0);
+        oracle_rectify(s0.data, w, h, s0.step, w0.data(), w, h, w, ia);
+        oracle_rectify(s1.data, w, h, s1.step, w1.data(), w, h, w, ib);
+        oracle_disparity_ref(w0.data(), w1.data(), w, h, w, wd.data(), w);
+        int nz = 0;
+        for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+            if (r0.at<uint8_t>(y, x) != w0[(size_t)y * w + x] || r1.at<uint8_t>(y, x) != w1[(size_t)y * w + x]) ++fails;
+            if (depth.at<uint8_t>(y, x) != wd[(size_t)y * w + x]) ++fails;
+            nz += wd[(size_t)y * w + x] != 0;
+        }
+        if (nz < w * h / 2) ++fails;
+        // a Mat that was NOT produced by the last two warps takes the upload path: same answer
+        cv::Mat copy0(h, w, 0);
+        for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) copy0.at<uint8_t>(y, x) = r0.at<uint8_t>(y, x);
+        cv::Mat depth2 = ComputeDepthImage(copy0, r1);
+        for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x)
+            if (depth2.at<uint8_t>(y, x) != wd[(size_t)y * w + x]) ++fails;
+        // swapped arguments use the slots the other way round
+        cv::Mat depth3 = ComputeDepthImage(r1, r0);
+        oracle_disparity_ref(w1.data(), w0.data(), w, h, w, wd.data(), w);
+        for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x)
+            if (depth3.at<uint8_t>(y, x) != wd[(size_t)y * w + x]) ++fails;
+        std::printf("R,R->D resident fails so far: %d\n", fails);
+    }
+    // ---- more than one GPU from one process: the multi-device handle ------------------------
+    {
+        const int nd = stx_device_count();
+        const int w = 260, h = 40, n = 5;
+        std::vector<uint8_t> a((size_t)n * w * h), b((size_t)n * w * h), got((size_t)n * w * h), want((size_t)w * h);
+        for (size_t i = 0; i < a.size(); ++i) { a[i] = rnd() % 25 == 0 ? 0 : rnd() % 256; b[i] = rnd() % 25 == 0 ? 0 : rnd() % 256; }
+        for (int use = 1; use <= (nd >= 2 ? 2 : 1); ++use) {
+            stx_multi *m = nullptr;
+            if (stx_multi_create(&m, nullptr, use) != STX_OK || stx_multi_size(m) != use) { ++fails; break; }
+            if (stx_disparity_batch_u8(m, a.data(), b.data(), n, w, h, w, (size_t)w * h, 1, 0, STX_COST_SAD, got.data(), w,
+                                       (size_t)w * h) != STX_OK) ++fails;
+            for (int k = 0; k < n; ++k) {
+                oracle_disparity_ref(a.data() + (size_t)k * w * h, b.data() + (size_t)k * w * h, w, h, w, want.data(), w);
+                if (std::memcmp(want.data(), got.data() + (size_t)k * w * h, want.size()) != 0) ++fails;
+            }
+            std::fill(got.begin(), got.end(), 0);
+            if (stx_disparity_rowband_u8(m, a.data(), b.data(), w, h, w, 1, 0, STX_COST_SAD, got.data(), w) != STX_OK) ++fails;
+            oracle_disparity_ref(a.data(), b.data(), w, h, w, want.data(), w);
+            if (std::memcmp(want.data(), got.data(), want.size()) != 0) ++fails;
+            stx_multi_destroy(m);
+        }
+        std::printf("multi-device fails so far: %d (%d device(s) visible)\n", fails, nd);
     }
     std::printf(fails ? "DROPIN FAIL\n" : "DROPIN OK\n");
     return fails ? 1 : 0;

@@ -295,6 +295,40 @@ def test_host_pipeline_equals_plain_copies(ctx, oracle, threads, chunks):
     assert (plain[5] == oracle.rectify(src, dst0.copy(), Hinv)).all()
 
 
+def test_resident_rectified_images_feed_the_scan(ctx, oracle):
+    """stx_rectify_u8_keep x2 + stx_disparity_resident_u8: main.cpp:362-380 with the two rectified
+    images never uploaded again; both pipeline settings; stale or mismatched slots are refused."""
+    from stereo_amd import StereoHipError
+    h, w = 200, 520
+    a, b = synth.texture(21, h, w), synth.texture(22, h, w)
+    i0 = oracle.invert3x3(synth.homography(1, w, h, deg_y=1.0))
+    i1 = oracle.invert3x3(synth.homography(2, w, h, deg_y=-1.5))
+    r0 = oracle.rectify(a, np.zeros((h, w), np.uint8), i0)
+    r1 = oracle.rectify(b, np.zeros((h, w), np.uint8), i1)
+    for on in (True, False):
+        ctx.set_host_pipeline(on, 0, 0)
+        try:
+            g0, g1 = np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8)
+            ctx.rectify_keep(0, a, g0, i0)
+            ctx.rectify_keep(1, b, g1, i1)
+            assert (g0 == r0).all() and (g1 == r1).all()
+            # other calls in between leave the resident images alone
+            ctx.disparity(a, b, win=3, max_disp=16)
+            ctx.rectify(a, np.zeros((h, w), np.uint8), i1)
+            for win, D, cm in [(1, 0, 0), (9, 64, 0), (13, 40, 1)]:
+                got = ctx.disparity_resident(0, 1, (h, w), win=win, max_disp=D, cost_mode=cm)
+                assert (got == oracle.disparity_ext(r0, r1, win, D, cm, sliding=D > 0)).all()
+            assert (ctx.disparity_resident(1, 0, (h, w)) == oracle.disparity_ref(r1, r0)).all()
+            with pytest.raises(StereoHipError):
+                ctx.disparity_resident(0, 1, (h, w - 1))       # not the resident size
+            small = np.zeros((10, 12), np.uint8)
+            ctx.rectify_keep(1, a, small, i0)                   # slot 1 now holds a 12 x 10 image
+            with pytest.raises(StereoHipError):
+                ctx.disparity_resident(0, 1, (h, w))
+        finally:
+            ctx.set_host_pipeline(True, 0, 0)
+
+
 def test_entry_points_leave_the_callers_device_alone(ctx):
     """Every entry point restores the thread's current device (one GPU here: it must stay 0 and
     torch must keep working between calls)."""
