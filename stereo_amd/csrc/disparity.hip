@@ -386,7 +386,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     // PK (SAD windows): a window cost is below 2^15, so the column sums of two disparities, d
     // and d + 8, share one register as half-words (v_sad_u8 / v_sad_hi_u8 add a tap to either
     // half); the row-leaving subtraction and the whole horizontal slide then run once per PAIR
-    // of disparities.  key = cost << 16 | (65535 - d).  Disparities past D start from PK_PAST per
+    // of disparities.  key = cost << 16 | x1 (the candidate's img1 column, carried by the mask row).  Disparities past D start from PK_PAST per
     // column, which lifts their costs above every valid one (PK_PAST > 255 * WIN) without
     // leaving the half-word (WIN * (PK_PAST + 255 * WIN) < 65536).
     // 13x13 and 15x15 (PKW): costs reach 255 * 225 < 2^16, so a key may pass 2^31 and neither the
@@ -490,7 +490,11 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
             const int i = tid + k * (int)blockDim.x;
             if (i < rw) {
                 Rrow[slot * rw + i] = fill_r[k] << PSH;
-                Mrow[slot * rw + i] = fill_r[k] ? 0u : (PK ? PK_MASKED : SSDW ? SSDW_MASKED : BAND_MASKED);
+                // PK: the low half of a mask word is the img1 COLUMN x1 of the candidate -- the key's
+                // tie-break code (lower x1 wins, the reference's first-wins order) travels with the
+                // mask, so a key is one shift-or / and-or of (cost, mask word)
+                Mrow[slot * rw + i] = PK ? ((fill_r[k] ? 0u : PK_MASKED) | ((unsigned)(rbase + i) & 0xFFFFu))
+                                         : fill_r[k] ? 0u : (SSDW ? SSDW_MASKED : BAND_MASKED);
             }
         }
     };
@@ -501,13 +505,16 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     // the constant, so each window cost comes out as (cost << 12) + (4095 - d) with no extra
     // instruction.  Disparities past D (partial last block) carry BAND_PAST_D the same way.
     unsigned V[PK ? BAND_ND / 2 : BAND_ND][4];
-    unsigned code_lo[PK ? BAND_ND / 2 : 1], code_hi[PK ? BAND_ND / 2 : 1];
+    // PKW only: all-ones for a disparity past D (the half-word bias cannot mark it there)
+    unsigned past_lo[PKW ? BAND_ND / 2 : 1], past_hi[PKW ? BAND_ND / 2 : 1];
     if constexpr (PK) {
 #pragma unroll
         for (int pp = 0; pp < BAND_ND / 2; ++pp) {
             const int dlo = dB + pp, dhi = dB + pp + BAND_ND / 2;
-            code_lo[pp] = PKW && dlo >= a.D ? ~0u : LOW - (unsigned)dlo;
-            code_hi[pp] = PKW && dhi >= a.D ? ~0u : LOW - (unsigned)dhi;
+            if constexpr (PKW) {
+                past_lo[pp] = dlo >= a.D ? ~0u : 0u;
+                past_hi[pp] = dhi >= a.D ? ~0u : 0u;
+            }
             const unsigned init = (dlo < a.D ? 0u : PK_PAST) | ((dhi < a.D ? 0u : PK_PAST) << 16);
 #pragma unroll
             for (int c = 0; c < 4; ++c) V[pp][c] = init;
@@ -690,8 +697,13 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         // the two half-word costs become two keys; mask word: 0 or BAND_MASKED
-                        const unsigned klo = ((cost[c] << 16) | code_lo[dd]) | mv[16 + c - dd];
-                        const unsigned khi = ((cost[c] & 0xFFFF0000u) | code_hi[dd]) | mv[16 + c - dd - BAND_ND / 2];
+                        // mask word: x1 in the low half, 0 or PK_MASKED above it
+                        unsigned klo = (cost[c] << 16) | mv[16 + c - dd];
+                        unsigned khi = (cost[c] & 0xFFFF0000u) | mv[16 + c - dd - BAND_ND / 2];
+                        if constexpr (PKW) {
+                            klo |= past_lo[dd];
+                            khi |= past_hi[dd];
+                        }
                         m[c] = min3_u32(m[c], klo, khi);
                     }
                 } else
@@ -745,7 +757,8 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
                     else if (key >= INIT)
                         v = x;  // no valid candidate: xBest stays 0
                     else
-                        v = (int)(LOW - (key & LOW)) + (SSD ? a.dbase : 0);  // d = x - xBest
+                        v = PK ? (int)(((unsigned)x - key) & LOW)  // the key's code is xBest (mod 2^16)
+                               : (int)(LOW - (key & LOW)) + (SSD ? a.dbase : 0);  // d = x - xBest
                     uint8_t *orow = a.out + pair * a.out_pair_stride + (size_t)(y - a.row0) * a.out_stride;
                     if (a.out_bytes == 1)
                         orow[x] = (uint8_t)(v & 0xFF);
@@ -1054,7 +1067,7 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
     const int D = max_disp < w ? max_disp : w;  // candidates beyond column 0 do not exist
     const bool ssd = cost_mode == STX_COST_SSD && r > 0;  // a single tap orders candidates as SAD does
     // (the band kernel addresses an image through 32-bit buffer offsets: one image below 2 GiB)
-    if (r <= 7 && D <= 4096 && !ctx->force_bruteforce && (unsigned long long)stride * (unsigned)h < (1ull << 31)) {
+    if (r <= 7 && D <= 4096 && w < 65536 && !ctx->force_bruteforce && (unsigned long long)stride * (unsigned)h < (1ull << 31)) {
         BandArgs a;
         a.img0 = d_img0; a.img1 = d_img1; a.w = w; a.h = h; a.stride = stride;
         a.pair_stride = pair_stride; a.row0 = row0; a.rows = rows; a.bh = rows; a.D = D;
