@@ -1,0 +1,240 @@
+"""A second, independent restatement of the three hot-path functions in numpy, written from the
+reference source without looking at oracle/stereo_oracle.c's control flow, against the C oracle
+on seeded random inputs -- bit for bit.
+
+This does NOT pin the oracle to the reference (the reference holds no vectors for M, R and D and
+cannot be built here: parity stays "unpinned").  It removes one failure mode: a slip
+of the pen in one restatement would have to be made identically in the other.  The two differ in
+method where the arithmetic allows it: the disparity costs below come from integral images (the C
+oracle sums taps, or slides column sums), the reference scan from whole-row distance matrices, the
+warp is evaluated for all pixels at once, the distances accumulate over k for all pairs at once.
+
+    M  stereo/Features.cpp:806-815, 1007-1079        R  stereo/Stereography.cpp:577-631
+    D  stereo/Stereography.cpp:649-691 (+ the D1-ext generalisation of DESIGN.md 3)
+"""
+import numpy as np
+import pytest
+
+from stereo_amd import synth
+
+f32 = np.float32
+
+
+# ------------------------------------------------------------------ D ----------
+
+def _depth_reference_mode(img0, img1):
+    """ComputeDepthImage, Stereography.cpp:664-688, one row at a time as a distance matrix."""
+    h, w = img0.shape
+    out = np.zeros((h, w), np.uint8)
+    xs = np.arange(w)
+    for y in range(h):
+        p0 = img0[y].astype(np.int32)
+        p1 = img1[y].astype(np.int32)
+        dist = np.abs(p1[None, :] - p0[:, None])          # [x, x1]
+        dist[:, p1 == 0] = 255                            # :676 skipped; 255 never beats the initial 255 (:672, strict <)
+        best = dist.argmin(axis=1)                        # first minimum = lowest x1 (:677)
+        best[dist.min(axis=1) >= 255] = 0                 # xBest stays 0 (:671)
+        v = np.abs(best - xs)                             # :686, then int -> uchar
+        v[p0 == 0] = 0                                    # :670
+        out[y] = (v & 0xFF).astype(np.uint8)
+    return out
+
+
+def _box_sum(a, r):
+    """Sum over the (2r+1)^2 window around every pixel of `a`, zero outside (integral image)."""
+    h, w = a.shape
+    p = np.zeros((h + 2 * r + 1, w + 2 * r + 1), np.int64)
+    p[r + 1:r + 1 + h, r + 1:r + 1 + w] = a
+    ii = p.cumsum(0).cumsum(1)
+    k = 2 * r + 1
+    return ii[k:k + h, k:k + w] - ii[:h, k:k + w] - ii[k:k + h, :w] + ii[:h, :w]
+
+
+def _depth_ext(img0, img1, win, D, ssd, dtype):
+    """D1-ext: win x win SAD/SSD over zero-extended images, candidates x1 in [max(0,x-D+1), x]
+    scanned in ascending x1, strict <, initial best 255*win^2 (65025*win^2)."""
+    h, w = img0.shape
+    r = win // 2
+    a = img0.astype(np.int64)
+    init = (65025 if ssd else 255) * win * win
+    best = np.full((h, w), init, np.int64)
+    xbest = np.zeros((h, w), np.int64)
+    for d in range(min(D, w) - 1, -1, -1):                # ascending x1 = descending d
+        # taps: |img1(x1+dx) - img0(x+dx)| with BOTH images zero outside their borders.  Shifting
+        # the zero-extended img1 by d keeps its zero extension, but img0's column x+dx and img1's
+        # column x1+dx fall outside their images at different places, so extend explicitly.
+        ext = r + d
+        a_e = np.zeros((h, w + 2 * ext), np.int64)
+        b_e = np.zeros((h, w + 2 * ext), np.int64)
+        a_e[:, ext:ext + w] = a
+        b_e[:, ext + d:ext + d + w] = img1
+        t = np.abs(b_e - a_e)
+        t = t * t if ssd else t
+        cost = _box_sum(t, r)[:, ext:ext + w]
+        cand = np.zeros((h, w), bool)
+        cand[:, d:] = img1[:, :w - d] != 0
+        win_ = cand & (cost < best)
+        best[win_] = cost[win_]
+        xbest[win_] = np.broadcast_to(np.arange(w)[None, :] - d, (h, w))[win_]
+    v = np.arange(w)[None, :] - xbest
+    v[img0 == 0] = 0
+    mask = 0xFF if np.dtype(dtype).itemsize == 1 else 0xFFFF
+    return (v & mask).astype(dtype)
+
+
+@pytest.mark.parametrize("h,w,seed", [(7, 40, 1), (12, 300, 2), (3, 513, 3)])
+def test_reference_mode_scan_two_restatements_agree(oracle, h, w, seed):
+    rng = np.random.RandomState(seed)
+    a = rng.randint(0, 256, (h, w)).astype(np.uint8)
+    b = rng.randint(0, 256, (h, w)).astype(np.uint8)
+    a[rng.rand(h, w) < 0.1] = 0
+    b[rng.rand(h, w) < 0.1] = 0
+    b[0] = 0                                              # a row without candidates
+    assert (oracle.disparity_ref(a, b) == _depth_reference_mode(a, b)).all()
+    l, r = synth.rectified_pair(seed, h, w, 32)
+    assert (oracle.disparity_ref(l, r) == _depth_reference_mode(l, r)).all()
+
+
+@pytest.mark.parametrize("win,D,ssd", [(1, 9, 0), (3, 16, 0), (5, 40, 1), (9, 24, 0), (13, 20, 1), (15, 33, 0),
+                                       (21, 12, 1), (9, 300, 0)])
+def test_windowed_scan_two_restatements_agree(oracle, win, D, ssd):
+    rng = np.random.RandomState(win * 100 + D)
+    h, w = (18, 70) if D < 100 else (6, 340)
+    a = rng.randint(0, 256, (h, w)).astype(np.uint8)
+    b = rng.randint(0, 256, (h, w)).astype(np.uint8)
+    a[rng.rand(h, w) < 0.05] = 0
+    b[rng.rand(h, w) < 0.05] = 0
+    b[:, 10:14] = a[:, 12:16]                             # some exact matches / ties
+    dt = np.uint16 if D > 256 else np.uint8
+    want = _depth_ext(a, b, win, D, ssd, dt)
+    assert (oracle.disparity_ext(a, b, win, D, ssd, dt) == want).all()
+    assert (oracle.disparity_ext(a, b, win, D, ssd, dt, sliding=True) == want).all()
+
+
+# ------------------------------------------------------------------ R ----------
+
+def _invert_cofactors(H):
+    """Matrix3f::inverse() as DESIGN.md 2 states it: cofactors / determinant, det = a0 + (a1 + a2),
+    every entry times 1/det."""
+    m = H.astype(f32)
+    c = np.zeros((3, 3), f32)
+    for i in range(3):
+        for j in range(3):
+            i1, i2, j1, j2 = (i + 1) % 3, (i + 2) % 3, (j + 1) % 3, (j + 2) % 3
+            c[i, j] = f32(m[i1, j1] * m[i2, j2]) - f32(m[i1, j2] * m[i2, j1])
+    det = f32(c[0, 0] * m[0, 0]) + f32(f32(c[1, 0] * m[1, 0]) + f32(c[2, 0] * m[2, 0]))
+    inv = f32(1) / det
+    return (c.T * inv).astype(f32)
+
+
+def _rectify_all_pixels(src, dst, Hinv):
+    """RectifyImage + BilinearInterpolatePixel, Stereography.cpp:577-631, for all pixels at once;
+    every statement is one rounded fp32 array operation."""
+    h, w = dst.shape
+    sh, sw = src.shape
+    X, Y = np.meshgrid(np.arange(w, dtype=f32), np.arange(h, dtype=f32))
+    hm = Hinv.astype(f32)
+    one = f32(1)
+
+    def row(k):   # 3x3 * 3x1, reduced as a0 + (a1 + a2)
+        return hm[k, 0] * X + (hm[k, 1] * Y + hm[k, 2] * one)
+
+    with np.errstate(all="ignore"):
+        z = row(2)
+        qx, qy = row(0) / z, row(1) / z                  # :618
+        inb = (0 < qx) & (qx < f32(sw - 1)) & (0 < qy) & (qy < f32(sh - 1))   # :621, :623 (NaN fails)
+        qx, qy = np.where(inb, qx, f32(0.5)), np.where(inb, qy, f32(0.5))
+        x1, x2, y1, y2 = np.floor(qx), np.ceil(qx), np.floor(qy), np.ceil(qy)
+        wx1, wx2 = (x2 - qx) / (x2 - x1), (qx - x1) / (x2 - x1)             # :584-587 (0/0 on integers)
+        wy1, wy2 = (y2 - qy) / (y2 - y1), (qy - y1) / (y2 - y1)
+        ix1, ix2 = x1.astype(np.int64), np.minimum(x2.astype(np.int64), max(sw - 1, 0))
+        iy1, iy2 = y1.astype(np.int64), np.minimum(y2.astype(np.int64), max(sh - 1, 0))
+        s = src.astype(f32)
+        r1 = wx1 * s[iy1, ix1] + wx2 * s[iy1, ix2]                         # :589
+        r2 = wx1 * s[iy2, ix1] + wx2 * s[iy2, ix2]                         # :590
+        nan_x = np.isnan(r1) | np.isnan(r2)
+        r1 = np.trunc(np.where(nan_x, f32(0), r1))                         # (uchar): NaN -> 0, else truncation
+        r2 = np.trunc(np.where(nan_x, f32(0), r2))
+        v = wy1 * r1 + wy2 * r2                                            # :592
+        v = np.trunc(np.where(np.isnan(v), f32(0), v))
+    out = dst.copy()
+    out[inb] = v[inb].astype(np.uint8)                                     # misses keep the destination
+    return out
+
+
+@pytest.mark.parametrize("h,w,seed", [(48, 64, 1), (50, 77, 2), (120, 333, 3)])
+def test_rectify_two_restatements_agree(oracle, h, w, seed):
+    if min(h, w) < 3:
+        pytest.skip("tiny")
+    src = synth.texture(seed, h, w)
+    rng = np.random.RandomState(seed)
+    for H in (synth.homography(seed, w, h, deg_y=2.0), synth.homography(seed + 9, w, h, deg_y=-1.0, deg_x=1.5),
+              np.array([[1, 0, 0.5], [0, 1, 0.25], [0, 0, 1]], f32),          # half-integer hits on one axis
+              np.eye(3, dtype=f32)):                                          # integer coordinates everywhere
+        hinv = _invert_cofactors(np.asarray(H, f32))
+        assert hinv.tobytes() == oracle.invert3x3(H).tobytes()
+        dst0 = rng.randint(0, 256, (h + 3, w - 5)).astype(np.uint8)            # a destination of another size
+        want = _rectify_all_pixels(src, dst0, hinv)
+        got = oracle.rectify(src, dst0.copy(), hinv)
+        assert (got == want).all(), np.argwhere(got != want)[:5]
+    assert (_rectify_all_pixels(src, np.zeros((h, w), np.uint8), _invert_cofactors(np.eye(3, dtype=f32))) == 0).all()
+
+
+# ------------------------------------------------------------------ M ----------
+
+def _distances(d1, d2):
+    """DistanceBetweenDescriptors + L2_norm (Features.cpp:806-815, 1007-1018) for all pairs:
+    k ascending, one fp32 accumulator, difference, square and sum each rounded."""
+    acc = np.zeros((len(d1), len(d2)), f32)
+    for k in range(128):
+        t = d1[:, k][:, None] - d2[:, k][None, :]
+        acc = acc + t * t
+    with np.errstate(invalid="ignore"):
+        return np.sqrt(acc)
+
+
+def _match(d1, s1, d2, s2, limit):
+    """MatchDescriptors, Features.cpp:1020-1079, as the scan it is written as."""
+    dist = _distances(d1, d2)
+    n1, n2 = dist.shape
+    out = [np.full(n1, -1, np.int32), np.full(n1, -1, np.int32), np.full(n1, -1, f32), np.full(n1, -1, f32),
+           np.zeros(n1, np.uint8)]
+    for i in range(n1):
+        closest, second, mind = -1, -1, f32(-1)
+        for j in range(n2):
+            if mind == f32(-1) or dist[i, j] < mind:      # :1041
+                second, closest, mind = closest, j, dist[i, j]
+        out[0][i], out[1][i], out[2][i] = closest, second, mind
+        if closest == -1 or second == -1 or closest == second:   # :1049
+            continue
+        out[3][i] = dist[i, second]
+        if abs(f32(s1[i]) - f32(s2[closest])) > f32(limit):      # :1057
+            out[4][i] = 1
+            continue
+        with np.errstate(all="ignore"):
+            ratio = f32(mind) / f32(dist[i, second])             # :1062
+        out[4][i] = 3 if float(ratio) < 0.8 else 2               # NN_RATIO is a double literal
+    return out
+
+
+@pytest.mark.parametrize("n1,n2,seed", [(40, 60, 1), (90, 33, 2)])
+def test_match_two_restatements_agree(oracle, n1, n2, seed):
+    d1, s1, d2, s2 = synth.descriptor_sets(seed, n1, n2)
+    d2[0] = d1[3]                      # nearest at j = 0
+    d2[5] = d1[4]
+    d2[9] = d1[4]                      # duplicates: first wins, ratio 0/0
+    s2[7] = s1[6] + 2000
+    d2[7] = d1[6]                      # score gate
+    d1[10] = 0
+    d2[20] = 0
+    d1[1, 5] = np.nan
+    d2[17, 9] = np.nan                 # NaN later in the scan is never < minDist
+    d1[2] *= f32(1e20)                 # squares overflow to inf
+    got = oracle.match(d1, s1, d2, s2, 1000.0)
+    want = _match(d1, s1, d2, s2, 1000.0)
+    for k, (g, w_) in enumerate(zip(got, want)):
+        if g.dtype == np.float32:
+            assert (((g.view(np.uint32) == w_.view(np.uint32)) | (np.isnan(g) & np.isnan(w_)))).all(), k
+        else:
+            assert g.tolist() == w_.tolist(), k
+    assert set(want[4].tolist()) >= {0, 1, 2, 3}
