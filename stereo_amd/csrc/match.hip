@@ -653,6 +653,56 @@ __global__ __launch_bounds__(256) void match_prep_frag_bf16x1_kernel(const float
     frag16[(jb / MF_TJ1) * MF_TILE_U4 + (jb % MF_TJ1) * 512 + (idx & 511)] = hi;
 }
 
+// The first MF_WARM_ROWS rows of list2 are handled apart, per query, in fp32 (match_warm_kernel):
+//   * they are scanned in order with the fp32 prefilter's bound (C = 2^-14): row j is a candidate
+//     unless an earlier row is clearly closer -- a handful of candidates instead of the whole
+//     first block a cold bound would emit (the x1 kernel never emits rows below MF_WARM_ROWS);
+//   * yw[q] = max over those rows of a.b_j - |b_j|^2 / 2 is a valid bound for every later row,
+//     so every piece of a query block, also one that starts in the middle of list2, starts warm.
+// Rows with a non-finite norm are always candidates and never part of the bound; a query that
+// yields nothing finite keeps -inf (= cold).  The candidates go to the query's last sub-list.
+constexpr int MF_WARM_ROWS = 32;
+__global__ __launch_bounds__(256) void match_warm_kernel(const float *__restrict__ desc1, const float *__restrict__ qnorm,
+                                                         int n1, const float *__restrict__ desc2, int n2,
+                                                         const float *__restrict__ bnorm, const float *__restrict__ bmax,
+                                                         float *__restrict__ yw, int nsub, int subcap,
+                                                         int *__restrict__ cand_count, int *__restrict__ cand)
+{
+    __shared__ float rows[MF_WARM_ROWS][K];
+    __shared__ float hn[MF_WARM_ROWS];
+    const int nr = n2 < MF_WARM_ROWS ? n2 : MF_WARM_ROWS;
+    for (int i = threadIdx.x; i < nr * K; i += 256) rows[i / K][i % K] = desc2[i];
+    if ((int)threadIdx.x < nr) hn[threadIdx.x] = 0.5f * bnorm[threadIdx.x];
+    __syncthreads();
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= n1) return;
+    float a[K];
+    const float4 *src = reinterpret_cast<const float4 *>(desc1 + (size_t)q * K);
+#pragma unroll
+    for (int k = 0; k < K / 4; ++k) {
+        const float4 v = src[k];
+        a[4 * k] = v.x; a[4 * k + 1] = v.y; a[4 * k + 2] = v.z; a[4 * k + 3] = v.w;
+    }
+    // on y = -(d~ - |a|^2) / 2 the test d~' + e < d~ - e reads y < y' - e
+    const float e = MF_C * (qnorm[q] + *bmax) + MF_TINY;
+    int *list = cand + ((size_t)q * nsub + (nsub - 1)) * subcap;
+    int cnt = 0;
+    float best = -__builtin_inff();
+    for (int j = 0; j < nr; ++j) {
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) dot = fmaf(a[k], rows[j][k], dot);
+        const float y = dot - hn[j];
+        if (!(y < best - e)) {  // NaN (non-finite norms) is always a candidate
+            if (cnt < subcap) list[cnt] = j;
+            ++cnt;
+        }
+        if (y > best && y < __builtin_inff()) best = y;  // NaN and +inf never enter the bound
+    }
+    cand_count[(size_t)q * nsub + (nsub - 1)] = cnt;
+    yw[q] = best;
+}
+
 struct BoundX1 {
     float Y;        // running max of y over the rows seen so far
     float T;        // Y - e: rows with y < T cannot be records
@@ -674,7 +724,7 @@ __device__ __forceinline__ void x1_emit(unsigned mask, int &cnt, int *__restrict
         mask &= ~(1u << bit);
         const int r = 15 - bit;
         const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (j < n2) {
+        if (j < n2 && j >= MF_WARM_ROWS) {  // the first rows are match_warm_kernel's
             if (cnt < subcap) list[cnt] = j;
             ++cnt;
         }
@@ -818,7 +868,7 @@ __global__ __launch_bounds__(X1_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
     const float *__restrict__ desc1, const float *__restrict__ qnorm, int n1,
     const uint4 *__restrict__ frag16, const float *__restrict__ bmax, int n2,
     int tiles_total, long long per, long long flat_total, int nsub, int subcap,
-    int *__restrict__ cand_count, int *__restrict__ cand)
+    int *__restrict__ cand_count, int *__restrict__ cand, const float *__restrict__ ywarm)
 {
     // Two separate LDS objects, not one [2][..] array: the tile staging is an LDS DMA
     // (global_load_lds) tracked by vmcnt, and the compiler only lets a ds_read pass an
@@ -902,6 +952,10 @@ __global__ __launch_bounds__(X1_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
         b0.e = MF_C_X1 * (na0 + nbmax) + MF_TINY;
         b1.e = MF_C_X1 * (na1 + nbmax) + MF_TINY;
         b0.Y = b1.Y = b0.M = b1.M = -__builtin_inff();
+        // every piece starts from the bound of list2's first rows (match_warm_kernel), which are
+        // that kernel's to emit
+        b0.Y = live0 ? ywarm[q0i] : b0.Y;
+        b1.Y = live1 ? ywarm[q1i] : b1.Y;
         b0.T = b0.Y - b0.e;
         b1.T = b1.Y - b1.e;
         b0.mask = b1.mask = 0;
@@ -1168,8 +1222,10 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     float *frag = (float *)stx_workspace(ctx, STX_SLOT_M_FRAG, sizeof(float) * (frag_floats + (size_t)n2pad + 4), &err);
     if (!frag) return err;
     float *bnorm = frag + frag_floats;
-    float *qnorm = (float *)stx_workspace(ctx, STX_SLOT_M_QNORM, sizeof(float) * (size_t)n1, &err);
+    // [qnorm n1][ywarm n1]
+    float *qnorm = (float *)stx_workspace(ctx, STX_SLOT_M_QNORM, sizeof(float) * 2 * (size_t)n1, &err);
     if (!qnorm) return err;
+    float *ywarm = qnorm + n1;
     // x1 kernel: one contiguous range of `per` tiles of the flattened (query block, tile) plane
     // per workgroup, 2 workgroups per CU; a query block is cut into at most max_pieces pieces
     const long long flat_total = (long long)qblocks * tiles_total;
@@ -1186,7 +1242,7 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     const int max_pieces = (int)((tiles_total + per - 1) / per) + 1;
     // candidate lists: one list of MF_CAP slots per query filled with atomics (fp32 / bf16x3
     // kernels), or two private sub-lists per piece (x1 kernel)
-    const int nsub = x1 ? 2 * max_pieces : 1;
+    const int nsub = x1 ? 2 * max_pieces + 1 : 1;  // x1: + the warm kernel's list
     const int subcap = x1 ? (nsub <= 8 ? 128 : nsub <= 16 ? 64 : 32) : MF_CAP;
     // [count n1*nsub][overflow_count 1 (+pad)][overflow_list n1][cand n1*nsub*subcap]
     const size_t n1a = ((size_t)n1 + 3) & ~(size_t)3;
@@ -1218,10 +1274,13 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
                            0, st, d_desc2, n2, n2pad, frag);
     hipLaunchKernelGGL(match_norm_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_desc1, n1, n1, qnorm,
                        (unsigned *)nullptr);
-    if (x1)
+    if (x1) {
+        hipLaunchKernelGGL(match_warm_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_desc1, qnorm, n1, d_desc2, n2,
+                           bnorm, reinterpret_cast<const float *>(bmax), ywarm, nsub, subcap, cnt, cand);
         hipLaunchKernelGGL(match_mfma_bf16x1_kernel, dim3(x1_wgs), dim3(X1_WAVES * 64), 0, st, d_desc1, qnorm,
                            n1, reinterpret_cast<const uint4 *>(frag), reinterpret_cast<const float *>(bmax), n2,
-                           tiles_total, per, flat_total, nsub, subcap, cnt, cand);
+                           tiles_total, per, flat_total, nsub, subcap, cnt, cand, ywarm);
+    }
     else if (bf16)
         hipLaunchKernelGGL(match_mfma_bf16_kernel, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm,
                            n1, reinterpret_cast<const uint4 *>(frag), bnorm, n2, tiles_total, tiles_per_seg, cnt,
