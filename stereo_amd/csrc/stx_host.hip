@@ -217,13 +217,33 @@ int stx_host_chunks(stx_ctx *ctx, size_t bytes, size_t units)
     return c;
 }
 
-// user rows -> pinned (workers) -> device (s_in), then ev is recorded on s_in
+// A caller whose buffers are already page-locked (hipHostMalloc, hipHostRegister, a pinned
+// cv::MatAllocator, torch pin_memory) needs no staging copy at all: the DMA engines read and write
+// its memory directly.  [p, p + bytes) must lie inside one registered allocation.
+bool stx_host_is_pinned(const void *p, size_t bytes)
+{
+    if (!p || bytes == 0) return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess || at.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return false;
+    }
+    hipPointerAttribute_t end;
+    if (hipPointerGetAttributes(&end, (const char *)p + bytes - 1) != hipSuccess || end.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}
+
+// user rows -> pinned (workers) -> device (s_in), then ev is recorded on s_in.
+// pin == nullptr: the user's rows are dense and page-locked, the DMA reads them directly.
 int stx_host_upload(stx_ctx *ctx, void *d_dst, void *pin, const void *src, size_t spitch, size_t wbytes,
                     size_t rows, hipEvent_t ev)
 {
     if (rows > 0 && wbytes > 0) {
-        pool_copy2d(ctx, pin, wbytes, src, spitch, wbytes, rows);
-        STX_HIP(hipMemcpyAsync(d_dst, pin, wbytes * rows, hipMemcpyHostToDevice, ctx->s_in));
+        if (pin) pool_copy2d(ctx, pin, wbytes, src, spitch, wbytes, rows);
+        STX_HIP(hipMemcpyAsync(d_dst, pin ? pin : src, wbytes * rows, hipMemcpyHostToDevice, ctx->s_in));
     }
     if (ev) STX_HIP(hipEventRecord(ev, ctx->s_in));
     return STX_OK;
@@ -239,12 +259,13 @@ int stx_host_download_begin(stx_ctx *ctx, void *pin, const void *d_src, size_t b
     return STX_OK;
 }
 
-// wait for ev, then pinned -> user rows (workers)
+// wait for ev, then pinned -> user rows (workers).  pin == dst: the download went straight into
+// the user's (dense, page-locked) rows.
 int stx_host_download_end(stx_ctx *ctx, void *dst, size_t dpitch, const void *pin, size_t wbytes, size_t rows,
                           hipEvent_t ev)
 {
     STX_HIP(hipEventSynchronize(ev));
-    if (rows > 0 && wbytes > 0) pool_copy2d(ctx, dst, dpitch, pin, wbytes, wbytes, rows);
+    if (rows > 0 && wbytes > 0 && pin != dst) pool_copy2d(ctx, dst, dpitch, pin, wbytes, wbytes, rows);
     return STX_OK;
 }
 
@@ -330,6 +351,10 @@ int stx_disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, i
         rc = fence_copy_streams(ctx);
         if (rc) return rc;
         uint8_t *pin_in = (uint8_t *)ctx->pin_ptr[0], *pin_out = (uint8_t *)ctx->pin_ptr[1];
+        // page-locked, dense caller buffers are read / written by the DMA engines directly
+        const bool in0_direct = stride == p && stx_host_is_pinned(img0 + (size_t)b0 * stride, img);
+        const bool in1_direct = stride == p && stx_host_is_pinned(img1 + (size_t)b0 * stride, img);
+        const bool out_direct = out_stride == op && stx_host_is_pinned(o, oimg);
         // chunk c uploads input rows [u(c), u(c+1)) of the band and computes the output rows
         // whose windows end inside what has been uploaded so far
         int up_prev = 0, out_prev = 0;  // band-relative input rows uploaded / output rows computed
@@ -338,9 +363,10 @@ int stx_disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, i
             const int up_next = c == nc - 1 ? bh : (int)((long long)bh * (c + 1) / nc);
             const size_t ro = (size_t)up_prev * p, rn = (size_t)(up_next - up_prev);
             const size_t uoff = (size_t)(b0 + up_prev) * stride;
-            rc = stx_host_upload(ctx, d0 + ro, pin_in + ro, img0 + uoff, stride, p, rn, nullptr);
+            rc = stx_host_upload(ctx, d0 + ro, in0_direct ? nullptr : pin_in + ro, img0 + uoff, stride, p, rn, nullptr);
             if (rc) return rc;
-            rc = stx_host_upload(ctx, d1 + ro, pin_in + img + ro, img1 + uoff, stride, p, rn, ctx->ev_in[c]);
+            rc = stx_host_upload(ctx, d1 + ro, in1_direct ? nullptr : pin_in + img + ro, img1 + uoff, stride, p, rn,
+                                 ctx->ev_in[c]);
             if (rc) return rc;
             up_prev = up_next;
             // output rows (relative to row0) computable now: image row y needs input rows up to
@@ -357,14 +383,16 @@ int stx_disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, i
                 if (rc) return rc;
             }
             STX_HIP(hipEventRecord(ctx->ev_k[c], ctx->stream));
-            rc = stx_host_download_begin(ctx, pin_out + (size_t)out_prev * op, dout + (size_t)out_prev * op,
-                                         (size_t)out_n[c] * op, ctx->ev_k[c], ctx->ev_out[c]);
+            rc = stx_host_download_begin(ctx, out_direct ? o + (size_t)out_prev * op : pin_out + (size_t)out_prev * op,
+                                         dout + (size_t)out_prev * op, (size_t)out_n[c] * op, ctx->ev_k[c],
+                                         ctx->ev_out[c]);
             if (rc) return rc;
             out_prev = out_next;
         }
         for (int c = 0; c < nc; ++c) {
             rc = stx_host_download_end(ctx, o + (size_t)out_lo[c] * out_stride, out_stride,
-                                       pin_out + (size_t)out_lo[c] * op, op, (size_t)out_n[c], ctx->ev_out[c]);
+                                       out_direct ? o + (size_t)out_lo[c] * op : pin_out + (size_t)out_lo[c] * op, op,
+                                       (size_t)out_n[c], ctx->ev_out[c]);
             if (rc) return rc;
         }
         return STX_OK;
@@ -465,18 +493,20 @@ int stx_rectify_host(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h, siz
     rc = fence_copy_streams(ctx);
     if (rc) return rc;
     uint8_t *pin_in = (uint8_t *)ctx->pin_ptr[0], *pin_out = (uint8_t *)ctx->pin_ptr[1];
+    const bool src_direct = have_src && src_stride == sp && stx_host_is_pinned(src, sbytes);
+    const bool dst_direct = dst_stride == dp && stx_host_is_pinned(dst, dbytes);
     // uploads: the source (and, to keep missed pixels, the destination) in row chunks so the
     // staging copy of chunk c+1 runs while chunk c is on the bus
     const int ncu = stx_host_chunks(ctx, sbytes, (size_t)(src_h > 0 ? src_h : 1));
     if (have_src)
         for (int c = 0; c < ncu; ++c) {
             const size_t r0 = (size_t)src_h * c / ncu, r1 = (size_t)src_h * (c + 1) / ncu;
-            rc = stx_host_upload(ctx, dsrc + r0 * sp, pin_in + r0 * sp, src + r0 * src_stride, src_stride, sp, r1 - r0,
-                                 nullptr);
+            rc = stx_host_upload(ctx, dsrc + r0 * sp, src_direct ? nullptr : pin_in + r0 * sp, src + r0 * src_stride,
+                                 src_stride, sp, r1 - r0, nullptr);
             if (rc) return rc;
         }
     if (preserve) {
-        rc = stx_host_upload(ctx, ddst, pin_in + sbytes, dst, dst_stride, dp, (size_t)dst_h, nullptr);
+        rc = stx_host_upload(ctx, ddst, dst_direct ? nullptr : pin_in + sbytes, dst, dst_stride, dp, (size_t)dst_h, nullptr);
         if (rc) return rc;
     }
     STX_HIP(hipEventRecord(ctx->ev_in[0], ctx->s_in));
@@ -491,12 +521,13 @@ int stx_rectify_host(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h, siz
                                         Hinv, flags);
         if (rc) return rc;
         STX_HIP(hipEventRecord(ctx->ev_k[c], ctx->stream));
-        rc = stx_host_download_begin(ctx, pin_out + (size_t)lo[c] * dp, ddst + (size_t)lo[c] * dp, (size_t)cnt[c] * dp,
-                                     ctx->ev_k[c], ctx->ev_out[c]);
+        rc = stx_host_download_begin(ctx, dst_direct ? dst + (size_t)lo[c] * dp : pin_out + (size_t)lo[c] * dp,
+                                     ddst + (size_t)lo[c] * dp, (size_t)cnt[c] * dp, ctx->ev_k[c], ctx->ev_out[c]);
         if (rc) return rc;
     }
     for (int c = 0; c < ncd; ++c) {
-        rc = stx_host_download_end(ctx, dst + (size_t)lo[c] * dst_stride, dst_stride, pin_out + (size_t)lo[c] * dp, dp,
+        rc = stx_host_download_end(ctx, dst + (size_t)lo[c] * dst_stride, dst_stride,
+                                   dst_direct ? dst + (size_t)lo[c] * dp : pin_out + (size_t)lo[c] * dp, dp,
                                    (size_t)cnt[c], ctx->ev_out[c]);
         if (rc) return rc;
     }
@@ -529,6 +560,7 @@ int stx_disparity_resident_host(stx_ctx *ctx, const uint8_t *d_img0, const uint8
     rc = fence_copy_streams(ctx);
     if (rc) return rc;
     uint8_t *pin_out = (uint8_t *)ctx->pin_ptr[1];
+    if (out_stride == op && stx_host_is_pinned(o, oimg)) pin_out = o;  // page-locked caller rows: direct
     const int nc = stx_host_chunks(ctx, oimg, (size_t)(h + 63) / 64);
     int lo[STX_HOST_MAX_CHUNKS], cnt[STX_HOST_MAX_CHUNKS];
     for (int c = 0; c < nc; ++c) {

@@ -295,6 +295,51 @@ def test_host_pipeline_equals_plain_copies(ctx, oracle, threads, chunks):
     assert (plain[5] == oracle.rectify(src, dst0.copy(), Hinv)).all()
 
 
+def test_page_locked_caller_buffers_skip_the_staging(ctx, oracle):
+    """Dense, page-locked caller arrays (torch pin_memory here; hipHostMalloc / a pinned
+    cv::MatAllocator in C++) are read and written by the DMA engines directly; mixed pinned /
+    pageable arguments and pinned-but-pitched views fall back per buffer.  Same bytes either way."""
+    import torch
+    h, w = 400, 1300
+    l, r = synth.rectified_pair(31, h, w, 300)
+    src = synth.texture(32, h, w)
+    Hinv = oracle.invert3x3(synth.homography(5, w, h))
+
+    def pinned(a):
+        t = torch.empty(a.shape, dtype=torch.uint8 if a.dtype == np.uint8 else torch.int16, pin_memory=True)
+        v = t.numpy().view(a.dtype)
+        v[...] = a
+        return t, v
+
+    tl, pl = pinned(l)
+    tr, pr = pinned(r)
+    ts, ps = pinned(src)
+    want9 = oracle.disparity_ext(l, r, 9, 64, 0, sliding=True)
+    want16 = oracle.disparity_ext(l, r, 5, 300, 0, np.uint16, sliding=True)
+    wantr = oracle.rectify(src, np.zeros_like(src), Hinv)
+    for on, chunks in ((True, 0), (True, 3), (False, 0)):
+        ctx.set_host_pipeline(on, 0, chunks)
+        try:
+            to, po = pinned(np.zeros((h, w), np.uint8))
+            assert (ctx.disparity(pl, pr, win=9, max_disp=64, out=po) == want9).all()
+            assert (ctx.disparity(pl, r, win=9, max_disp=64) == want9).all()          # img1 and out pageable
+            to16, po16 = pinned(np.zeros((h, w), np.uint16))
+            assert (ctx.disparity(pl, pr, win=5, max_disp=300, out_dtype=np.uint16, out=po16) == want16).all()
+            assert (ctx.disparity(pl[:, :900], pr[:, :900], win=9, max_disp=64)
+                    == oracle.disparity_ext(l[:, :900], r[:, :900], 9, 64, 0, sliding=True)).all()   # pitched views
+            td, pd = pinned(np.zeros_like(src))
+            ctx.rectify(ps, pd, Hinv, api.RECT_PRESERVE_DST)
+            assert (pd == wantr).all()
+            pd[...] = 7
+            ctx.rectify(ps, pd, Hinv, api.RECT_DST_IS_ZERO)
+            assert (pd == wantr).all()
+            ctx.rectify_keep(0, ps, pd, Hinv)
+            ctx.rectify_keep(1, ps, pd, Hinv)
+            assert (ctx.disparity_resident(0, 1, (h, w), out=po) == oracle.disparity_ref(wantr, wantr)).all()
+        finally:
+            ctx.set_host_pipeline(True, 0, 0)
+
+
 def test_resident_rectified_images_feed_the_scan(ctx, oracle):
     """stx_rectify_u8_keep x2 + stx_disparity_resident_u8: main.cpp:362-380 with the two rectified
     images never uploaded again; both pipeline settings; stale or mismatched slots are refused."""
@@ -327,6 +372,42 @@ def test_resident_rectified_images_feed_the_scan(ctx, oracle):
                 ctx.disparity_resident(0, 1, (h, w))
         finally:
             ctx.set_host_pipeline(True, 0, 0)
+
+
+def test_two_contexts_on_two_threads(oracle):
+    """One context per thread (the ABI's threading rule): two host threads, each with its own
+    context, staging threads and streams, run different host-pointer calls at the same time."""
+    import threading
+    import stereo_amd
+    l, r = synth.rectified_pair(77, 300, 1200, 64)
+    src = synth.texture(78, 300, 1200)
+    Hinv = oracle.invert3x3(synth.homography(4, 1200, 300))
+    want_d = oracle.disparity_ext(l, r, 9, 64, 0, sliding=True)
+    want_r = oracle.rectify(src, np.zeros_like(src), Hinv)
+    errors = []
+
+    def work(kind):
+        try:
+            c = stereo_amd.Context(0)
+            try:
+                for _ in range(12):
+                    if kind == 0:
+                        assert (c.disparity(l, r, win=9, max_disp=64) == want_d).all()
+                    else:
+                        d = np.zeros_like(src)
+                        c.rectify(src, d, Hinv, api.RECT_DST_IS_ZERO)
+                        assert (d == want_r).all()
+            finally:
+                c.close()
+        except Exception as e:  # noqa
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(k % 2,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
 
 
 def test_entry_points_leave_the_callers_device_alone(ctx):

@@ -47,6 +47,22 @@ for name, st in settings:
     row.append(best(lambda: ctx.match(d1, s1, d2, s2, 1000.0), 5))
     print("%-12s " % name + " ".join("%8.3f / %8.3f ms" % v for v in row), flush=True)
 ctx.set_host_pipeline(True, 0, 0)
+# page-locked caller buffers (torch pin_memory; hipHostMalloc in C++): no staging copies
+import torch
+
+
+def pinned(a):
+    t = torch.empty(a.shape, dtype=torch.uint8, pin_memory=True)
+    v = t.numpy()
+    v[...] = a
+    return t, v
+
+
+keep = [pinned(x) for x in (l, r, dout, src, dst)]
+pl, pr, pdout, psrc, pdst = [k[1] for k in keep]
+row = [best(lambda: ctx.disparity(pl, pr, win=9, max_disp=D, out=pdout)), best(lambda: ctx.disparity(pl, pr, out=pdout), 7),
+       best(lambda: ctx.rectify(psrc, pdst, Hinv)), best(lambda: ctx.rectify(psrc, pdst, Hinv, stereo_amd.api.RECT_DST_IS_ZERO))]
+print("%-12s " % "pinned t0 c0" + " ".join("%8.3f / %8.3f ms" % v for v in row), flush=True)
 b, m = best(lambda: mc.disparity_batch(ba, bb, win=9, max_disp=192), 5)
 print("stx_disparity_batch_u8, 32 x 1080p pairs, D=192, 1 device: best %.2f ms median %.2f ms = %.0f pairs/s" % (b, m, 32 / m * 1e3))
 print("(best / median of the calls; outputs written into reused arrays except for the fused call and matching)")
