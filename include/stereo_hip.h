@@ -124,6 +124,17 @@ int stx_match(stx_ctx *ctx, const float *desc1, const float *score1, int n1,
               int32_t *closest, int32_t *second, float *min_dist,
               float *second_dist, uint8_t *status);
 
+/* stx_match on the reference's own layout: feat1 / feat2 point at arrays of n1 / n2 feature
+ * records of feature_stride bytes each -- std::vector<Feature>::data() with sizeof(Feature) = 540
+ * -- holding the 128-float descriptor at desc_offset (offsetof(Feature, desc) = 20) and the score
+ * at score_offset (offsetof(Feature, score) = 12); stride and offsets are multiples of 4.  The
+ * records are uploaded as they lie and split into descriptor / score arrays on the GPU, so the
+ * host never loops over the floats.  Outputs as stx_match.  Host pointers. */
+int stx_match_features(stx_ctx *ctx, const void *feat1, int n1, const void *feat2, int n2,
+                       size_t feature_stride, size_t desc_offset, size_t score_offset, float dist_limit,
+                       int32_t *closest, int32_t *second, float *min_dist, float *second_dist,
+                       uint8_t *status);
+
 /* Same with every array resident in device memory; asynchronous. */
 int stx_match_dev(stx_ctx *ctx, const float *d_desc1, const float *d_score1, int n1,
                   const float *d_desc2, const float *d_score2, int n2,

@@ -60,6 +60,8 @@ PROTOTYPES = {
                                   _vp, _vp, _vp, _vp, _vp]),
     "stx_match": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_float,
                             _vp, _vp, _vp, _vp, _vp]),
+    "stx_match_features": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float,
+                                     _vp, _vp, _vp, _vp, _vp]),
     "stx_match_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_float,
                                 _vp, _vp, _vp, _vp, _vp]),
     "stx_invert_homography": (C.c_int, [_f32p, _f32p]),

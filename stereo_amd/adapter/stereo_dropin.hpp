@@ -66,23 +66,18 @@ inline std::vector<std::pair<Feature, Feature> > MatchDescriptors(
 {
     using namespace stereo_hip_dropin;
     const int n1 = (int)list1.size(), n2 = (int)list2.size();
-    // AoS Feature (540 B, descriptor at offset 20) -> SoA descriptor / score arrays
-    std::vector<float> d1((size_t)n1 * STX_DESC_LEN), d2((size_t)n2 * STX_DESC_LEN), s1(n1), s2(n2);
-    for (int i = 0; i < n1; ++i) {
-        for (int k = 0; k < STX_DESC_LEN; ++k) d1[(size_t)i * STX_DESC_LEN + k] = list1[i].desc.vec[k];
-        s1[i] = list1[i].score;
-    }
-    for (int j = 0; j < n2; ++j) {
-        for (int k = 0; k < STX_DESC_LEN; ++k) d2[(size_t)j * STX_DESC_LEN + k] = list2[j].desc.vec[k];
-        s2[j] = list2[j].score;
-    }
+    if (n1 == 0) return std::vector<std::pair<Feature, Feature> >();  // the outer loop at :1028 never runs
+    // The feature records go up as they lie in the vectors (540-byte Feature, descriptor at
+    // offset 20, score at 12); the GPU splits them into descriptor / score arrays.
     std::vector<int32_t> closest(n1), second(n1);
     std::vector<float> minDist(n1), secondDist(n1);
     std::vector<uint8_t> status(n1);
-    check(stx_match(context(), d1.data(), s1.data(), n1, d2.data(), s2.data(), n2,
-                    distLimitBetweenMatches, closest.data(), second.data(), minDist.data(),
-                    secondDist.data(), status.data()),
-          "stx_match");
+    check(stx_match_features(context(), list1.data(), n1, list2.data(), n2, sizeof(Feature),
+                             (size_t)((const char *)&list1.data()->desc - (const char *)list1.data()),
+                             (size_t)((const char *)&list1.data()->score - (const char *)list1.data()),
+                             distLimitBetweenMatches, closest.data(), second.data(), minDist.data(),
+                             secondDist.data(), status.data()),
+          "stx_match_features");
     std::vector<std::pair<Feature, Feature> > matches;
     for (int i = 0; i < n1; ++i) {
         if (status[i] == STX_MATCH_FAILED) {

@@ -122,6 +122,28 @@ class Context:
                                   _ptr(status)), "stx_match")
         return closest, second, min_dist, second_dist, status
 
+    def match_features(self, rec1, rec2, desc_offset, score_offset, dist_limit=MAX_DIST_BETWEEN_MATCHES):
+        """match() on arrays of feature RECORDS (the reference's std::vector<Feature> layout):
+        rec1 / rec2 are [n, stride_bytes] uint8 arrays (or structured arrays) holding the 128-float
+        descriptor at desc_offset and the score at score_offset of every record."""
+        r1 = np.ascontiguousarray(rec1).view(np.uint8).reshape(len(rec1), -1)
+        r2 = np.ascontiguousarray(rec2).view(np.uint8).reshape(len(rec2), -1) if len(rec2) else np.zeros((0, r1.shape[1]), np.uint8)
+        if len(rec1) == 0:
+            r1 = np.zeros((0, r2.shape[1]), np.uint8)
+        if r1.shape[1] != r2.shape[1]:
+            raise ValueError("both lists must use the same record size")
+        n1, n2, stride = r1.shape[0], r2.shape[0], r1.shape[1]
+        closest = np.full(n1, -1, np.int32)
+        second = np.full(n1, -1, np.int32)
+        min_dist = np.full(n1, -1.0, np.float32)
+        second_dist = np.full(n1, -1.0, np.float32)
+        status = np.zeros(n1, np.uint8)
+        check(self._lib.stx_match_features(self._h, _ptr(r1) if n1 else None, n1, _ptr(r2) if n2 else None, n2, stride,
+                                           int(desc_offset), int(score_offset), C.c_float(dist_limit), _ptr(closest),
+                                           _ptr(second), _ptr(min_dist), _ptr(second_dist), _ptr(status)),
+              "stx_match_features")
+        return closest, second, min_dist, second_dist, status
+
     def match_dev(self, desc1, score1, desc2, score2, dist_limit, closest, second, min_dist,
                   second_dist, status):
         """torch device tensors in and out; asynchronous on the context's stream."""

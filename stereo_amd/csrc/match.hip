@@ -1297,3 +1297,34 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     return launch_exact(ctx, d_desc1, d_score1, n1, d_desc2, d_score2, n2, dist_limit, ovf_list, ovf_count,
                         d_closest, d_second, d_min_dist, d_second_dist, d_status);
 }
+
+// ---------------------------------------------------------------------------
+// Array-of-structures input (the reference's std::vector<Feature>, Features.h:52-84: 540-byte
+// records, descriptor at byte offset 20, score at 12): the records are uploaded as they lie in
+// the caller's vector and split into the descriptor and score arrays here, instead of a host
+// loop that touches every float once more.
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void match_unpack_aos_kernel(const unsigned char *__restrict__ rec, int n,
+                                                               size_t stride, size_t desc_off, size_t score_off,
+                                                               float *__restrict__ desc, float *__restrict__ score)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // (feature, k)
+    const size_t i = idx / K;
+    const int k = (int)(idx % K);
+    if (i >= (size_t)n) return;
+    const unsigned char *r = rec + i * stride;
+    desc[idx] = *reinterpret_cast<const float *>(r + desc_off + 4 * (size_t)k);  // offsets are multiples of 4
+    if (k == 0) score[i] = *reinterpret_cast<const float *>(r + score_off);
+}
+}  // namespace
+
+int stx_launch_unpack_features(stx_ctx *ctx, const void *d_rec, int n, size_t stride, size_t desc_off,
+                               size_t score_off, float *d_desc, float *d_score)
+{
+    if (n <= 0) return STX_OK;
+    const size_t total = (size_t)n * K;
+    hipLaunchKernelGGL(match_unpack_aos_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       static_cast<const unsigned char *>(d_rec), n, stride, desc_off, score_off, d_desc, d_score);
+    return (int)hipGetLastError();
+}

@@ -239,6 +239,60 @@ extern "C" int stx_match(stx_ctx *ctx, const float *desc1, const float *score1, 
     return STX_OK;
 }
 
+extern "C" int stx_match_features(stx_ctx *ctx, const void *feat1, int n1, const void *feat2, int n2,
+                                  size_t feature_stride, size_t desc_offset, size_t score_offset, float dist_limit,
+                                  int32_t *closest, int32_t *second, float *min_dist, float *second_dist,
+                                  uint8_t *status)
+{
+    if (!ctx || n1 < 0 || n2 < 0) return STX_ERR_INVALID_ARG;
+    if ((n1 > 0 && !feat1) || (n2 > 0 && !feat2)) return STX_ERR_INVALID_ARG;
+    if ((feature_stride & 3) || (desc_offset & 3) || (score_offset & 3) ||
+        desc_offset + sizeof(float) * STX_DESC_LEN > feature_stride || score_offset + sizeof(float) > feature_stride)
+        return STX_ERR_INVALID_ARG;
+    STX_ENTER(ctx);
+    if (n1 == 0) return STX_OK;
+    int err;
+    const size_t r1b = (size_t)n1 * feature_stride, r2b = (size_t)n2 * feature_stride;
+    const size_t d1b = (size_t)n1 * STX_DESC_LEN * sizeof(float), d2b = (size_t)n2 * STX_DESC_LEN * sizeof(float);
+    unsigned char *drec = (unsigned char *)stx_workspace(ctx, STX_SLOT_AOS, r1b + r2b, &err);
+    if (!drec) return err;
+    float *dd1 = (float *)stx_workspace(ctx, STX_SLOT_DESC1, d1b, &err);
+    if (!dd1) return err;
+    float *dd2 = (float *)stx_workspace(ctx, STX_SLOT_DESC2, d2b, &err);
+    if (!dd2) return err;
+    const size_t n1a = ((size_t)n1 + 63) & ~(size_t)63, n2a = ((size_t)n2 + 63) & ~(size_t)63;
+    char *sm = (char *)stx_workspace(ctx, STX_SLOT_SMALL, 4 * n1a + 4 * n2a + 4 * 4 * n1a + n1a, &err);
+    if (!sm) return err;
+    float *ds1 = (float *)sm;
+    float *ds2 = (float *)(sm + 4 * n1a);
+    int32_t *dcl = (int32_t *)(sm + 4 * n1a + 4 * n2a);
+    int32_t *dse = dcl + n1a;
+    float *dmd = (float *)(dse + n1a);
+    float *dsd = dmd + n1a;
+    uint8_t *dst = (uint8_t *)(dsd + n1a);
+    hipStream_t s = ctx->stream;
+    // list2 first: its preparation (norms, fragments) depends on nothing in list1
+    if (stx_host_pipeline_on(ctx)) {
+        int prc = stx_host_prepare(ctx, r1b + r2b, 0);
+        if (prc) return prc;
+        prc = stx_host_fence(ctx);
+        if (prc) return prc;
+    }
+    int rc = stx_host_upload_flat(ctx, drec + r1b, feat2, r2b, r1b);
+    if (!rc) rc = stx_host_upload_flat(ctx, drec, feat1, r1b, 0);
+    if (!rc) rc = stx_launch_unpack_features(ctx, drec + r1b, n2, feature_stride, desc_offset, score_offset, dd2, ds2);
+    if (!rc) rc = stx_launch_unpack_features(ctx, drec, n1, feature_stride, desc_offset, score_offset, dd1, ds1);
+    if (!rc) rc = stx_launch_match(ctx, dd1, ds1, n1, dd2, ds2, n2, dist_limit, dcl, dse, dmd, dsd, dst);
+    if (rc) return rc;
+    if (closest) STX_HIP(hipMemcpyAsync(closest, dcl, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
+    if (second) STX_HIP(hipMemcpyAsync(second, dse, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
+    if (min_dist) STX_HIP(hipMemcpyAsync(min_dist, dmd, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
+    if (second_dist) STX_HIP(hipMemcpyAsync(second_dist, dsd, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
+    if (status) STX_HIP(hipMemcpyAsync(status, dst, (size_t)n1, hipMemcpyDeviceToHost, s));
+    STX_HIP(hipStreamSynchronize(s));
+    return STX_OK;
+}
+
 // ---------------------------------------------------------------- R (host) --
 
 // Eigen 3.3 compute_inverse<Matrix3f,3> operation order (third-party arithmetic

@@ -28,6 +28,7 @@ enum stx_slot {
     STX_SLOT_RANSAC,     // hypothesis scoring: records + per-pair errors
     STX_SLOT_RES0,       // resident image 0 (stx_rectify_u8_keep -> stx_disparity_resident_u8)
     STX_SLOT_RES1,       // resident image 1
+    STX_SLOT_AOS,        // stx_match_features: the caller's feature records as uploaded
     STX_SLOT_COUNT
 };
 
@@ -148,6 +149,9 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
                      const float *d_desc2, const float *d_score2, int n2,
                      float dist_limit, int32_t *d_closest, int32_t *d_second,
                      float *d_min_dist, float *d_second_dist, uint8_t *d_status);
+
+int stx_launch_unpack_features(stx_ctx *ctx, const void *d_rec, int n, size_t stride, size_t desc_off,
+                               size_t score_off, float *d_desc, float *d_score);
 
 int stx_launch_fast(stx_ctx *ctx, const uint8_t *d_img, int w, int h, size_t stride, int threshold,
                     float *d_xy, int max_out, int *d_count);

@@ -59,6 +59,7 @@ def test_null_context_is_rejected_without_touching_a_gpu():
     assert lib.stx_rectify_u8_keep(None, 0, None, 4, 4, 4, None, 4, 4, 4, None, 0) == -1
     assert lib.stx_disparity_resident_u8(None, 0, 1, 4, 4, 1, 0, 0, None, 4) == -1
     assert lib.stx_disparity_dev_noalloc(None, None, None, 1, 4, 4, 4, 16, 1, 0, 0, None, 4, 16, 1) == -1
+    assert lib.stx_match_features(None, None, 0, None, 0, 540, 20, 12, C.c_float(1.0), None, None, None, None, None) == -1
     assert lib.stx_set_host_pipeline(None, 1, 0, 0) == -1
     assert lib.stx_multi_size(None) == -1
     assert lib.stx_multi_context(None, 0) is None

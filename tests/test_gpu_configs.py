@@ -247,6 +247,33 @@ def test_descriptor_file_replayed_through_stx_match(ctx, oracle, tmp_path):
     assert [m[1].p for m in matches] == [back[1].features[int(want[0][i])].p for i in acc]
 
 
+def test_match_on_feature_records(ctx, oracle):
+    """stx_match_features: the reference's std::vector<Feature> layout (540-byte records, score at
+    byte 12, descriptor at byte 20) uploaded as it lies and split on the GPU -- same outputs as
+    stx_match on the separate arrays, for the exact scan and the MFMA path, with both pipelines."""
+    feature = np.dtype([("scale", np.int32), ("p", np.float32, 2), ("score", np.float32), ("angle", np.float32),
+                        ("desc", np.float32, 128), ("distFromBestMatch", np.float32), ("depth", np.float32)])
+    assert feature.itemsize == 540 and feature.fields["desc"][1] == 20 and feature.fields["score"][1] == 12
+    for n1, n2 in ((70, 90), (3000, 2500), (1, 1), (5, 0)):
+        d1, s1, d2, s2 = synth.descriptor_sets(n1 + n2, max(n1, 1), max(n2, 1))
+        d2, s2 = d2[:n2], s2[:n2]
+        r1, r2 = np.zeros(n1, feature), np.zeros(n2, feature)
+        r1["desc"], r1["score"], r1["angle"] = d1, s1, 123.0      # the other fields are noise to the matcher
+        r2["desc"], r2["score"], r2["depth"] = d2, s2, -5.0
+        want = oracle.match(d1, s1, d2, s2, 1000.0)
+        for on in (True, False):
+            ctx.set_host_pipeline(on, 0, 0)
+            try:
+                _match_equal(ctx.match_features(r1, r2, 20, 12, 1000.0), want)
+            finally:
+                ctx.set_host_pipeline(True, 0, 0)
+    from stereo_amd import StereoHipError
+    with pytest.raises(StereoHipError):
+        ctx.match_features(r1, r1, 18, 12)      # misaligned descriptor offset
+    with pytest.raises(StereoHipError):
+        ctx.match_features(r1, r1, 40, 12)      # descriptor would leave the record
+
+
 # ------------------------------------------------- the host-pointer data path ----
 
 @pytest.mark.parametrize("threads,chunks", [(1, 1), (4, 0), (3, 8), (8, 3)])

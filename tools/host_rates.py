@@ -66,3 +66,15 @@ print("%-12s " % "pinned t0 c0" + " ".join("%8.3f / %8.3f ms" % v for v in row),
 b, m = best(lambda: mc.disparity_batch(ba, bb, win=9, max_disp=192), 5)
 print("stx_disparity_batch_u8, 32 x 1080p pairs, D=192, 1 device: best %.2f ms median %.2f ms = %.0f pairs/s" % (b, m, 32 / m * 1e3))
 print("(best / median of the calls; outputs written into reused arrays except for the fused call and matching)")
+# matching at config 5's size through host pointers: separate arrays vs the reference's 540-byte records
+n = 200000
+d1, s1, d2, s2 = synth.descriptor_sets(42, n, n)
+feature = np.dtype([("scale", np.int32), ("p", np.float32, 2), ("score", np.float32), ("angle", np.float32),
+                    ("desc", np.float32, 128), ("distFromBestMatch", np.float32), ("depth", np.float32)])
+r1, r2 = np.zeros(n, feature), np.zeros(n, feature)
+r1["desc"], r1["score"], r2["desc"], r2["score"] = d1, s1, d2, s2
+t0 = time.perf_counter()
+pk = (np.ascontiguousarray(r1["desc"]), np.ascontiguousarray(r1["score"]), np.ascontiguousarray(r2["desc"]), np.ascontiguousarray(r2["score"]))
+t_pack = (time.perf_counter() - t0) * 1e3
+print("stx_match 200k x 200k, host arrays:    best %.2f ms median %.2f ms  (+ %.1f ms to split the records on the host, numpy)" % (best(lambda: ctx.match(d1, s1, d2, s2, 1000.0), 3) + (t_pack,)))
+print("stx_match_features 200k x 200k records: best %.2f ms median %.2f ms  (records uploaded as they lie)" % best(lambda: ctx.match_features(r1, r2, 20, 12, 1000.0), 3))
