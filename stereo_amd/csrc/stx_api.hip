@@ -185,6 +185,17 @@ extern "C" int stx_match_dev(stx_ctx *ctx, const float *d_desc1, const float *d_
                             d_closest, d_second, d_min_dist, d_second_dist, d_status);
 }
 
+// Large host-pointer matching calls run list1 in query chunks (queries are independent): chunk
+// c + 1 is staged and uploaded while chunk c is matched, so of the two uploads only list2's stays
+// in front of the compute.  (Each chunk repeats list2's preparation, ~0.1 ms at 200k rows.)
+static int match_query_chunk(int n1, int n2)
+{
+    if ((double)n1 * (double)n2 < 4.0e9 || n1 < 4 * 16384) return n1;
+    int chunk = (n1 + 3) / 4;
+    chunk = (chunk + 511) / 512 * 512;  // whole query blocks of the x1 kernel
+    return chunk;
+}
+
 extern "C" int stx_match(stx_ctx *ctx, const float *desc1, const float *score1, int n1,
                          const float *desc2, const float *score2, int n2, float dist_limit,
                          int32_t *closest, int32_t *second, float *min_dist,
@@ -223,12 +234,20 @@ extern "C" int stx_match(stx_ctx *ctx, const float *desc1, const float *score1, 
         prc = stx_host_fence(ctx);
         if (prc) return prc;
     }
-    int urc = stx_host_upload_flat(ctx, dd1, desc1, d1b, 0);
-    if (!urc) urc = stx_host_upload_flat(ctx, dd2, desc2, d2b, d1b);
-    if (!urc) urc = stx_host_upload_flat(ctx, ds1, score1, s1b, d1b + d2b);
-    if (!urc) urc = stx_host_upload_flat(ctx, ds2, score2, s2b, d1b + d2b + s1b);
-    if (urc) return urc;
-    int rc = stx_launch_match(ctx, dd1, ds1, n1, dd2, ds2, n2, dist_limit, dcl, dse, dmd, dsd, dst);
+    // list2 first (its preparation depends on nothing in list1), then list1 in query chunks
+    int rc = stx_host_upload_flat(ctx, dd2, desc2, d2b, d1b);
+    if (!rc) rc = stx_host_upload_flat(ctx, ds2, score2, s2b, d1b + d2b + s1b);
+    if (!rc) rc = stx_host_upload_flat(ctx, ds1, score1, s1b, d1b + d2b);
+    const int qc = match_query_chunk(n1, n2);
+    for (int q0 = 0; q0 < n1 && !rc; q0 += qc) {
+        const int q = n1 - q0 < qc ? n1 - q0 : qc;
+        const size_t off = (size_t)q0 * STX_DESC_LEN;
+        rc = stx_host_upload_flat(ctx, dd1 + off, desc1 + off, sizeof(float) * (size_t)q * STX_DESC_LEN,
+                                  sizeof(float) * off);
+        if (!rc)
+            rc = stx_launch_match(ctx, dd1 + off, ds1 + q0, q, dd2, ds2, n2, dist_limit, dcl + q0, dse + q0, dmd + q0,
+                                  dsd + q0, dst + q0);
+    }
     if (rc != STX_OK) return rc;
     if (closest) STX_HIP(hipMemcpyAsync(closest, dcl, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
     if (second) STX_HIP(hipMemcpyAsync(second, dse, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
@@ -279,10 +298,19 @@ extern "C" int stx_match_features(stx_ctx *ctx, const void *feat1, int n1, const
         if (prc) return prc;
     }
     int rc = stx_host_upload_flat(ctx, drec + r1b, feat2, r2b, r1b);
-    if (!rc) rc = stx_host_upload_flat(ctx, drec, feat1, r1b, 0);
     if (!rc) rc = stx_launch_unpack_features(ctx, drec + r1b, n2, feature_stride, desc_offset, score_offset, dd2, ds2);
-    if (!rc) rc = stx_launch_unpack_features(ctx, drec, n1, feature_stride, desc_offset, score_offset, dd1, ds1);
-    if (!rc) rc = stx_launch_match(ctx, dd1, ds1, n1, dd2, ds2, n2, dist_limit, dcl, dse, dmd, dsd, dst);
+    const int qc = match_query_chunk(n1, n2);
+    for (int q0 = 0; q0 < n1 && !rc; q0 += qc) {  // list1 in query chunks: upload c + 1 behind match c
+        const int q = n1 - q0 < qc ? n1 - q0 : qc;
+        const size_t roff = (size_t)q0 * feature_stride;
+        rc = stx_host_upload_flat(ctx, drec + roff, (const unsigned char *)feat1 + roff, (size_t)q * feature_stride, roff);
+        if (!rc)
+            rc = stx_launch_unpack_features(ctx, drec + roff, q, feature_stride, desc_offset, score_offset,
+                                            dd1 + (size_t)q0 * STX_DESC_LEN, ds1 + q0);
+        if (!rc)
+            rc = stx_launch_match(ctx, dd1 + (size_t)q0 * STX_DESC_LEN, ds1 + q0, q, dd2, ds2, n2, dist_limit, dcl + q0,
+                                  dse + q0, dmd + q0, dsd + q0, dst + q0);
+    }
     if (rc) return rc;
     if (closest) STX_HIP(hipMemcpyAsync(closest, dcl, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
     if (second) STX_HIP(hipMemcpyAsync(second, dse, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));

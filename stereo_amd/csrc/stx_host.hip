@@ -591,6 +591,12 @@ int stx_host_upload_flat(stx_ctx *ctx, void *d_dst, const void *src, size_t byte
 {
     if (bytes == 0) return STX_OK;
     if (!stx_host_pipeline_on(ctx)) return (int)hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (stx_host_is_pinned(src, bytes)) {  // page-locked caller array: DMA it as it lies
+        STX_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->s_in));
+        STX_HIP(hipEventRecord(ctx->ev_in[0], ctx->s_in));
+        STX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_in[0], 0));
+        return STX_OK;
+    }
     uint8_t *pin = (uint8_t *)ctx->pin_ptr[0] + pin_off;
     const size_t chunk = (size_t)8 << 20;
     for (size_t off = 0; off < bytes; off += chunk) {
