@@ -14,10 +14,11 @@ oc = torch.empty(n, dtype=torch.int32, device="cuda"); os_ = torch.empty_like(oc
 om = torch.empty(n, dtype=torch.float32, device="cuda"); od = torch.empty_like(om)
 ot = torch.empty(n, dtype=torch.uint8, device="cuda")
 f = lambda: ctx.match_dev(t[0], t[1], t[2], t[3], 1000.0, oc, os_, om, od, ot)
-f(); torch.cuda.synchronize()
+for _ in range(3): f()
+torch.cuda.synchronize()
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(5): f()
+for _ in range(10): f()
 e1.record(); torch.cuda.synchronize()
-print(os.path.basename(os.environ.get("STEREO_HIP_LIB", "default")), "ms/call %.3f" % (e0.elapsed_time(e1) / 5),
+print(os.path.basename(os.environ.get("STEREO_HIP_LIB", "default")), "ms/call %.3f" % (e0.elapsed_time(e1) / 10),
       "accepted", int((ot == 3).sum().item()))
