@@ -45,7 +45,7 @@ def gather_rows(local, counts, dst=0, group=None):
         return local
     if rank == dst:
         parts = []
-        reqs = []
+        ops = []
         for r in range(world):
             if r == dst:
                 parts.append(local)
@@ -54,12 +54,14 @@ def gather_rows(local, counts, dst=0, group=None):
                               device=local.device)
             parts.append(buf)
             if counts[r] > 0:
-                reqs.append(dist.irecv(buf, src=r, group=group))
-        for q in reqs:
+                ops.append(dist.P2POp(dist.irecv, buf, r, group))
+        # one group: on RCCL the receives are posted together and run on all links at once
+        for q in (dist.batch_isend_irecv(ops) if ops else []):
             q.wait()
         return torch.cat(parts, dim=0)
     if local.shape[0] > 0:
-        dist.isend(local.contiguous(), dst=dst, group=group).wait()
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), dst, group)]):
+            q.wait()
     return None
 
 
