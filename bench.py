@@ -124,6 +124,104 @@ def units_evaluated(w, h, d):
     return per_row * h
 
 
+def config1_chain(ctx, orc, api, synth, reps=5):
+    """BASELINE config 1 (main.cpp:188-380 on a quarter-res pair) stage by stage: the host-pointer
+    calls of the library -- what the drop-in delivers, PCIe included -- beside the oracle on one
+    host thread, same inputs, outputs compared.  Stand-ins as in tests/test_gpu_configs.py: a
+    synthetic 741x500 pair, box-blur / central-difference gradient images instead of OpenCV's,
+    seeded K R K^-1 homographies instead of ComputeRectificationRotations, and the 200 RANSAC
+    hypotheses drawn once on the host (the eight-point solves stay the reference's host code)."""
+    from stereo_amd import ransac as rsc
+    h, w = 500, 741
+    imgs = synth.rectified_pair(1001, h, w, 48, zero_frac=0.0)
+    grads = [synth.gradient_stand_ins(im) for im in imgs]
+    kern = ctx.gaussian_kernel()
+    f = 3979.911 / 4
+    K = np.array([[f, 0, 311.0], [0, f, 255.0], [0, 0, 1]], np.float32)
+    hinv = [ctx.invert_homography(synth.homography(5, w, h, deg_y=0.8, deg_x=0.2)),
+            ctx.invert_homography(synth.homography(6, w, h, deg_y=-0.6, deg_x=0.3))]
+
+    def best_ms(fn, n=reps):
+        fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return min(ts), r
+
+    def once_ms(fn):
+        t0 = time.perf_counter()
+        r = fn()
+        return (time.perf_counter() - t0) * 1e3, r
+
+    gpu, cpu, same = {}, {}, {}
+    # features of both images
+    g_fast = [None, None]; g_sc = [None, None]; g_desc = [None, None]
+    c_fast = [None, None]; c_sc = [None, None]; c_desc = [None, None]
+    gpu["fast12"], _ = best_ms(lambda: [g_fast.__setitem__(k, ctx.fast_detect(imgs[k])[0]) for k in (0, 1)])
+    cpu["fast12"], _ = once_ms(lambda: [c_fast.__setitem__(k, orc.fast_features(imgs[k])) for k in (0, 1)])
+    same["fast12"] = all(np.array_equal(g_fast[k], np.asarray(c_fast[k], np.float32).reshape(-1, 2)) for k in (0, 1))
+    gpu["score_nms"], _ = best_ms(lambda: [g_sc.__setitem__(k, ctx.score_cluster(grads[k][0], grads[k][1], g_fast[k], kern,
+                                                                                 api.ST_THRESH, api.NMS_WINDOW)) for k in (0, 1)])
+    cpu["score_nms"], _ = once_ms(lambda: [c_sc.__setitem__(k, orc.score_and_cluster(grads[k][0], grads[k][1], c_fast[k], kern,
+                                                                                     api.ST_THRESH, api.NMS_WINDOW)) for k in (0, 1)])
+    same["score_nms"] = all(g_sc[k][0].tobytes() == np.asarray(c_sc[k][0], np.float32).tobytes()
+                            and g_sc[k][1].tobytes() == np.asarray(c_sc[k][1], np.float32).tobytes() for k in (0, 1))
+    gpu["sift_descriptors"], _ = best_ms(lambda: [g_desc.__setitem__(k, ctx.sift_descriptors(grads[k][0], grads[k][1], g_sc[k][0])[1])
+                                                  for k in (0, 1)])
+    cpu["sift_descriptors"], _ = once_ms(lambda: [c_desc.__setitem__(k, orc.sift_descriptors(grads[k][0], grads[k][1], c_sc[k][0])[1])
+                                                  for k in (0, 1)])
+    same["sift_descriptors"] = all(np.array_equal(g_desc[k].view(np.uint32), c_desc[k].view(np.uint32)) for k in (0, 1))
+    # MatchDescriptors
+    gpu["match"], gm = best_ms(lambda: ctx.match(g_desc[0], g_sc[0][1], g_desc[1], g_sc[1][1], 1000.0))
+    cpu["match"], cm = once_ms(lambda: orc.match(c_desc[0], c_sc[0][1], c_desc[1], c_sc[1][1], 1000.0))
+    same["match"] = bool(np.array_equal(gm[0], cm[0]) and np.array_equal(gm[1], cm[1]) and np.array_equal(gm[4], cm[4])
+                         and gm[2].tobytes() == cm[2].tobytes())
+    acc = np.nonzero(cm[4] == api.MATCH_ACCEPTED)[0]
+    p1 = np.ascontiguousarray(c_sc[0][0][acc], np.float32)
+    p2 = np.ascontiguousarray(c_sc[1][0][cm[0][acc]], np.float32)
+    # the pair loop of FindFundamentalMatrixWithRANSAC over 200 hypotheses
+    rng = rsc.msvc_rand(7)
+    recs, excl = [], []
+    for _ in range(4 * api.FUNDAMENTAL_RANSAC_ITERATIONS):
+        if len(recs) == api.FUNDAMENTAL_RANSAC_ITERATIONS or len(p1) < 8:
+            break
+        ch = rsc.draw_eight(len(p1), rng)
+        okf, f8 = rsc.find_fundamental_matrix(p1[ch], p2[ch])
+        rec = rsc.hypothesis_record(f8, K, K) if okf and np.all(np.isfinite(f8)) else None
+        if rec is not None:
+            recs.append(rec)
+            excl.append(ch)
+    if recs:
+        recs, excl = np.stack(recs), np.array(excl, np.int32)
+        gpu["ransac_score"], gr = best_ms(lambda: ctx.ransac_score(recs, K, K, p1, p2, exclude=excl))
+        cpu["ransac_score"], cr = once_ms(lambda: orc.ransac_score(recs, K, K, p1, p2, excl,
+                                                                  api.FUNDAMENTAL_REPROJECTION_ERROR_THRESHOLD))
+        same["ransac_score"] = bool(np.array_equal(gr[0], cr[0]) and gr[1].tobytes() == np.asarray(cr[1], np.float32).tobytes())
+    # RectifyImage x 2 + ComputeDepthImage as written (1x1, whole row)
+    gpu["rectify_x2_disparity"], gd = best_ms(lambda: ctx.rectify_disparity(imgs[0], imgs[1], hinv[0], hinv[1], win=1, max_disp=0))
+
+    def cpu_rd():
+        r0 = orc.rectify(imgs[0], np.zeros((h, w), np.uint8), hinv[0])
+        r1 = orc.rectify(imgs[1], np.zeros((h, w), np.uint8), hinv[1])
+        return orc.disparity_ref(r0, r1)
+    cpu["rectify_x2_disparity"], cd = once_ms(cpu_rd)
+    gd = gd[0] if isinstance(gd, tuple) else gd
+    same["rectify_x2_disparity"] = bool((gd == cd).all())
+    return {
+        "workload": "741x500 synthetic pair: FAST-12, Shi-Tomasi + NMS and descriptors of both images (%d / %d features), "
+                    "MatchDescriptors (%d accepted), %d RANSAC hypotheses scored, RectifyImage x 2 + ComputeDepthImage "
+                    "(1x1, whole row)" % (len(g_sc[0][0]), len(g_sc[1][0]), len(acc), len(recs)),
+        "gpu_ms": gpu, "gpu_ms_total": sum(gpu.values()),
+        "cpu_ms": cpu, "cpu_ms_total": sum(cpu.values()), "cpu_cores": 1,
+        "gpu_equals_cpu": same,
+        "note": "gpu_ms: best of %d blocking host-pointer calls per stage (uploads and downloads included); cpu_ms: the "
+                "oracle, one call, one thread (ransac_score: one thread per hypothesis).  Host-only steps of the chain "
+                "(eight-point solves, rotations) are the reference's own code and not timed." % reps,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -653,6 +751,9 @@ def main():
                 "value": rh * rw / dt_r / 1e6, "unit": "Mpix/s", "cores": 1,
                 "sample": "oracle_rectify, one %dx%d image (%.2f s, single thread, inverse hoisted)" % (rw, rh, dt_r),
                 "matches_gpu_on_sample": bool((cr == dstt[0].cpu().numpy()).all())}
+
+            # BASELINE config 1 as a chain, stage by stage, GPU library beside the oracle
+            out["extra"]["config1_chain"] = config1_chain(ctx, orc, api, synth)
 
     if rank == 0:
         print(json.dumps(out))

@@ -1168,6 +1168,115 @@ __global__ __launch_bounds__(64) void match_replay_kernel(
         status_out[i] = match_status(closest, second, min_dist, second_dist, score1[i], score2, dist_limit);
 }
 
+// ---------------------------------------------------------------------------
+// Small problems (a few hundred features per image, BASELINE config 1): the scan of the exact
+// kernel is one dependent chain of n2 x 384 operations per query, ~2 us per row, so 200 rows
+// take 0.4 ms whatever the GPU.  Here RP_L lanes share a query and take every RP_L-th row of
+// list2; the two lexicographic (distance, index) minima of the replay kernel -- the same
+// argument: the scan's `closest` is the first index of the smallest distance, its `second` the
+// first index of the smallest distance among j < closest -- then replay the scan over ALL rows.
+// Distances are in the reference's operation order; they are kept in LDS for the second minimum
+// when n2 fits (STORE), else recomputed.
+// ---------------------------------------------------------------------------
+constexpr int SMALL_STORE_MAX = 8192;  // rows whose distances fit the LDS next to the queries (4 x 32 KiB)
+
+__device__ __forceinline__ float small_dist(const float *__restrict__ q, const float *__restrict__ brow)
+{
+    const float4 *b = reinterpret_cast<const float4 *>(brow);
+    float norm = 0.0f;
+#pragma unroll 8
+    for (int k4 = 0; k4 < K / 4; ++k4) {  // reference order: k ascending, one accumulator
+        const float4 bv = b[k4];
+        const float4 qv = reinterpret_cast<const float4 *>(q)[k4];
+        float d;
+        d = qv.x - bv.x; norm = norm + d * d;
+        d = qv.y - bv.y; norm = norm + d * d;
+        d = qv.z - bv.z; norm = norm + d * d;
+        d = qv.w - bv.w; norm = norm + d * d;
+    }
+    return sqrtf(norm);
+}
+
+template <bool STORE>
+__global__ __launch_bounds__(64) void match_small_kernel(
+    const float *__restrict__ desc1, const float *__restrict__ score1, int n1,
+    const float *__restrict__ desc2, const float *__restrict__ score2, int n2, float dist_limit,
+    int32_t *__restrict__ closest_out, int32_t *__restrict__ second_out,
+    float *__restrict__ min_dist_out, float *__restrict__ second_dist_out, uint8_t *__restrict__ status_out)
+{
+    extern __shared__ float small_lds[];  // STORE: [RP_G][n2] distances
+    __shared__ __attribute__((aligned(16))) float q_[RP_G][K];
+    const int g = threadIdx.x / RP_L;
+    const int l = threadIdx.x % RP_L;
+    const int i = blockIdx.x * RP_G + g;
+    const bool live = i < n1;
+    float *q = q_[g];
+    float *dist = small_lds + (size_t)g * (STORE ? n2 : 0);
+    if (live)
+        for (int k = l; k < K; k += RP_L) q[k] = desc1[(size_t)i * K + k];
+    __syncthreads();
+    const float inf = __builtin_inff();
+    float bd = inf, d0 = 0.0f;
+    int bj = 0x7FFFFFFF;
+    bool nan0 = false;
+    if (live) {
+#pragma unroll 1
+        for (int j = l; j < n2; j += RP_L) {
+            const float dt = small_dist(q, desc2 + (size_t)j * K);
+            if (STORE) dist[j] = dt;
+            if (j == 0) { nan0 = dt != dt; d0 = dt; }  // list2[0] is taken unconditionally (:1041)
+            const float dd = dt == dt ? dt : inf;     // a later NaN never satisfies dist < minDist
+            if (dd < bd || (dd == bd && j < bj)) { bd = dd; bj = j; }  // (+inf rows too: the first one stays)
+        }
+    }
+#pragma unroll
+    for (int m = RP_L / 2; m > 0; m >>= 1) {
+        const float od = __shfl_xor(bd, m);
+        const int oj = __shfl_xor(bj, m);
+        if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+        nan0 |= (bool)__shfl_xor((int)nan0, m);
+        const float o0 = __shfl_xor(d0, m);
+        d0 = (o0 != 0.0f || o0 != o0) ? o0 : d0;  // only the lane that met j == 0 holds a value
+    }
+    __syncthreads();  // (STORE) the group's distances are visible to all its lanes
+    int closest = -1, second = -1;
+    float min_dist = -1.0f, second_dist = -1.0f;
+    if (live && n2 > 0) {
+        if (nan0) {
+            closest = 0;
+            min_dist = d0;
+        } else {
+            closest = bj;
+            min_dist = bd;
+            float sd = inf;
+            int sj = 0x7FFFFFFF;
+#pragma unroll 1
+            for (int j = l; j < closest; j += RP_L) {
+                const float dt = STORE ? dist[j] : small_dist(q, desc2 + (size_t)j * K);
+                const float dd = dt == dt ? dt : inf;
+                if (dd < sd || (dd == sd && j < sj)) { sd = dd; sj = j; }
+            }
+#pragma unroll
+            for (int m = RP_L / 2; m > 0; m >>= 1) {
+                const float od = __shfl_xor(sd, m);
+                const int oj = __shfl_xor(sj, m);
+                if (od < sd || (od == sd && oj < sj)) { sd = od; sj = oj; }
+            }
+            if (sj != 0x7FFFFFFF) {
+                second = sj;
+                second_dist = sd;
+            }
+        }
+    }
+    if (l != 0 || !live) return;
+    if (closest_out) closest_out[i] = closest;
+    if (second_out) second_out[i] = second;
+    if (min_dist_out) min_dist_out[i] = min_dist;
+    if (second_dist_out) second_dist_out[i] = second_dist;
+    if (status_out)
+        status_out[i] = match_status(closest, second, min_dist, second_dist, score1[i], score2, dist_limit);
+}
+
 }  // namespace
 
 static int launch_exact(stx_ctx *ctx, const float *d_desc1, const float *d_score1, int n1,
@@ -1182,6 +1291,24 @@ static int launch_exact(stx_ctx *ctx, const float *d_desc1, const float *d_score
     return (int)hipGetLastError();
 }
 
+static int launch_small(stx_ctx *ctx, const float *d_desc1, const float *d_score1, int n1, const float *d_desc2,
+                        const float *d_score2, int n2, float dist_limit, int32_t *d_closest, int32_t *d_second,
+                        float *d_min_dist, float *d_second_dist, uint8_t *d_status)
+{
+    const int blocks = (n1 + RP_G - 1) / RP_G;
+    if (n2 <= SMALL_STORE_MAX) {
+        const int lds = (int)(sizeof(float) * RP_G * (size_t)n2);
+        const int rc = stx_set_lds_attr(ctx, reinterpret_cast<const void *>(match_small_kernel<true>), lds);
+        if (rc != STX_OK) return rc;
+        hipLaunchKernelGGL(match_small_kernel<true>, dim3(blocks), dim3(64), lds, ctx->stream, d_desc1, d_score1, n1,
+                           d_desc2, d_score2, n2, dist_limit, d_closest, d_second, d_min_dist, d_second_dist, d_status);
+    } else {
+        hipLaunchKernelGGL(match_small_kernel<false>, dim3(blocks), dim3(64), 0, ctx->stream, d_desc1, d_score1, n1,
+                           d_desc2, d_score2, n2, dist_limit, d_closest, d_second, d_min_dist, d_second_dist, d_status);
+    }
+    return (int)hipGetLastError();
+}
+
 int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, int n1,
                      const float *d_desc2, const float *d_score2, int n2, float dist_limit,
                      int32_t *d_closest, int32_t *d_second, float *d_min_dist,
@@ -1189,8 +1316,15 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
 {
     if (n1 <= 0) return STX_OK;
     int algo = ctx->match_algo;
-    if (algo == STX_MATCH_AUTO)
-        algo = ((double)n1 * (double)n2 >= 4.0e6 && n2 >= 1024) ? STX_MATCH_MFMA_BF16X1 : STX_MATCH_EXACT;
+    if (algo == STX_MATCH_AUTO) {
+        if ((double)n1 * (double)n2 >= 4.0e6 && n2 >= 1024)
+            algo = STX_MATCH_MFMA_BF16X1;
+        else if (n2 > 0)
+            return launch_small(ctx, d_desc1, d_score1, n1, d_desc2, d_score2, n2, dist_limit, d_closest, d_second,
+                                d_min_dist, d_second_dist, d_status);
+        else
+            algo = STX_MATCH_EXACT;
+    }
     if (algo == STX_MATCH_EXACT || n2 == 0)
         return launch_exact(ctx, d_desc1, d_score1, n1, d_desc2, d_score2, n2, dist_limit, nullptr,
                             nullptr, d_closest, d_second, d_min_dist, d_second_dist, d_status);

@@ -196,6 +196,32 @@ static int match_query_chunk(int n1, int n2)
     return chunk;
 }
 
+// The five result arrays lie back to back in the workspace (n1a elements apart).  Up to 64k queries
+// they come back in ONE copy into pinned memory and are split on the host: for a few hundred
+// features (BASELINE config 1) five pageable copies of a few hundred bytes each cost more than
+// the matching itself.  Larger results go straight to the caller's arrays.
+static int match_download(stx_ctx *ctx, int n1, size_t n1a, const int32_t *dcl, int32_t *closest, int32_t *second,
+                          float *min_dist, float *second_dist, uint8_t *status)
+{
+    hipStream_t s = ctx->stream;
+    const char *base = reinterpret_cast<const char *>(dcl);
+    void *dst[5] = {closest, second, min_dist, second_dist, status};
+    const size_t width[5] = {4, 4, 4, 4, 1};
+    const size_t all = 17 * n1a;
+    if (stx_host_pipeline_on(ctx) && n1 <= 65536 && ctx->pin_bytes[1] >= all) {
+        char *pin = static_cast<char *>(ctx->pin_ptr[1]);
+        STX_HIP(hipMemcpyAsync(pin, base, all, hipMemcpyDeviceToHost, s));
+        STX_HIP(hipStreamSynchronize(s));
+        for (int k = 0; k < 5; ++k)
+            if (dst[k]) memcpy(dst[k], pin + 4 * n1a * k, width[k] * (size_t)n1);
+        return STX_OK;
+    }
+    for (int k = 0; k < 5; ++k)
+        if (dst[k]) STX_HIP(hipMemcpyAsync(dst[k], base + 4 * n1a * k, width[k] * (size_t)n1, hipMemcpyDeviceToHost, s));
+    STX_HIP(hipStreamSynchronize(s));
+    return STX_OK;
+}
+
 extern "C" int stx_match(stx_ctx *ctx, const float *desc1, const float *score1, int n1,
                          const float *desc2, const float *score2, int n2, float dist_limit,
                          int32_t *closest, int32_t *second, float *min_dist,
@@ -225,11 +251,10 @@ extern "C" int stx_match(stx_ctx *ctx, const float *desc1, const float *score1, 
     float *dmd = (float *)(dse + n1a);
     float *dsd = dmd + n1a;
     uint8_t *dst = (uint8_t *)(dsd + n1a);
-    hipStream_t s = ctx->stream;
     // the two descriptor lists (config 5: 102 MB each) go through the staging pipeline
     const size_t s1b = 4 * (size_t)n1, s2b = 4 * (size_t)n2;
     if (stx_host_pipeline_on(ctx)) {
-        int prc = stx_host_prepare(ctx, d1b + d2b + s1b + s2b, 0);
+        int prc = stx_host_prepare(ctx, d1b + d2b + s1b + s2b, n1 <= 65536 ? 17 * n1a : 0);
         if (prc) return prc;
         prc = stx_host_fence(ctx);
         if (prc) return prc;
@@ -249,13 +274,7 @@ extern "C" int stx_match(stx_ctx *ctx, const float *desc1, const float *score1, 
                                   dsd + q0, dst + q0);
     }
     if (rc != STX_OK) return rc;
-    if (closest) STX_HIP(hipMemcpyAsync(closest, dcl, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
-    if (second) STX_HIP(hipMemcpyAsync(second, dse, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
-    if (min_dist) STX_HIP(hipMemcpyAsync(min_dist, dmd, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
-    if (second_dist) STX_HIP(hipMemcpyAsync(second_dist, dsd, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
-    if (status) STX_HIP(hipMemcpyAsync(status, dst, (size_t)n1, hipMemcpyDeviceToHost, s));
-    STX_HIP(hipStreamSynchronize(s));
-    return STX_OK;
+    return match_download(ctx, n1, n1a, dcl, closest, second, min_dist, second_dist, status);
 }
 
 extern "C" int stx_match_features(stx_ctx *ctx, const void *feat1, int n1, const void *feat2, int n2,
@@ -289,10 +308,9 @@ extern "C" int stx_match_features(stx_ctx *ctx, const void *feat1, int n1, const
     float *dmd = (float *)(dse + n1a);
     float *dsd = dmd + n1a;
     uint8_t *dst = (uint8_t *)(dsd + n1a);
-    hipStream_t s = ctx->stream;
     // list2 first: its preparation (norms, fragments) depends on nothing in list1
     if (stx_host_pipeline_on(ctx)) {
-        int prc = stx_host_prepare(ctx, r1b + r2b, 0);
+        int prc = stx_host_prepare(ctx, r1b + r2b, n1 <= 65536 ? 17 * n1a : 0);
         if (prc) return prc;
         prc = stx_host_fence(ctx);
         if (prc) return prc;
@@ -312,13 +330,7 @@ extern "C" int stx_match_features(stx_ctx *ctx, const void *feat1, int n1, const
                                   dse + q0, dmd + q0, dsd + q0, dst + q0);
     }
     if (rc) return rc;
-    if (closest) STX_HIP(hipMemcpyAsync(closest, dcl, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
-    if (second) STX_HIP(hipMemcpyAsync(second, dse, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
-    if (min_dist) STX_HIP(hipMemcpyAsync(min_dist, dmd, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
-    if (second_dist) STX_HIP(hipMemcpyAsync(second_dist, dsd, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
-    if (status) STX_HIP(hipMemcpyAsync(status, dst, (size_t)n1, hipMemcpyDeviceToHost, s));
-    STX_HIP(hipStreamSynchronize(s));
-    return STX_OK;
+    return match_download(ctx, n1, n1a, dcl, closest, second, min_dist, second_dist, status);
 }
 
 // ---------------------------------------------------------------- R (host) --
@@ -790,6 +802,21 @@ extern "C" int stx_score_cluster(stx_ctx *ctx, const uint8_t *gx, const uint8_t 
     rc = stx_launch_score_cluster(ctx, dgx, dgy, w, h, p, dxy, n, kernel3x3, score_threshold, cluster_dist,
                                   dxy_out, dscore, dindex, dcount);
     if (rc) return rc;
+    // [xy_out][score_out][index_out][count] lie back to back: up to 64k corners they come back in one
+    // copy through pinned memory and one wait (a few hundred corners per image in BASELINE config 1:
+    // the count's round trip and three more copies cost as much as the kernels)
+    const size_t out_all = sizeof(float) * 4 * (size_t)n + sizeof(int);
+    if (stx_host_pipeline_on(ctx) && n <= 65536 && stx_host_prepare(ctx, 0, out_all) == STX_OK) {
+        char *pin = static_cast<char *>(ctx->pin_ptr[1]);
+        STX_HIP(hipMemcpyAsync(pin, dxy_out, out_all, hipMemcpyDeviceToHost, s));
+        STX_HIP(hipStreamSynchronize(s));
+        memcpy(count, pin + sizeof(float) * 4 * (size_t)n, sizeof(int));
+        const size_t m = (size_t)*count;
+        memcpy(xy_out, pin, sizeof(float) * 2 * m);
+        memcpy(score_out, pin + sizeof(float) * 2 * (size_t)n, sizeof(float) * m);
+        memcpy(index_out, pin + sizeof(float) * 3 * (size_t)n, sizeof(int32_t) * m);
+        return STX_OK;
+    }
     STX_HIP(hipMemcpyAsync(count, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
     STX_HIP(hipStreamSynchronize(s));
     const size_t m = (size_t)*count;

@@ -148,3 +148,17 @@ def two_view_matches(seed, n, outlier_frac=0.3, noise=0.5, w=2880, h=1988):
     # (the products above are transposed views: force C order, [n,2] rows of (x, y))
     c = np.ascontiguousarray
     return c(k1, np.float32), c(k2, np.float32), c(p1, np.float32), c(p2, np.float32), c(fm, np.float32)
+
+
+def gradient_stand_ins(img):
+    """Stand-ins for the CV_8U GaussianBlur + Sobel images the reference makes with OpenCV
+    (Features.cpp:684-690; third-party arithmetic, out of scope): a 3x3 box blur and central
+    differences, negative values clipped to 0 as ddepth = CV_8U does.  What matters is that they
+    are functions of the image, so the two views' descriptors correspond."""
+    f = img.astype(np.float32)
+    p = np.pad(f, 1, mode="edge")
+    blur = sum(p[dy:dy + f.shape[0], dx:dx + f.shape[1]] for dy in range(3) for dx in range(3)) / 9.0
+    q = np.pad(blur, 1, mode="edge")
+    gx = q[1:-1, 2:] - q[1:-1, :-2]
+    gy = q[2:, 1:-1] - q[:-2, 1:-1]
+    return (np.clip(gx * 4, 0, 255).astype(np.uint8), np.clip(gy * 4, 0, 255).astype(np.uint8))

@@ -123,18 +123,7 @@ def test_config4_real_launch_1024_pairs(ctx, oracle):
 
 # ------------------------------------------------------------------ config 1 ----
 
-def _cv8u_gradients(img):
-    """Stand-ins for the CV_8U GaussianBlur + Sobel images the reference makes with OpenCV
-    (Features.cpp:684-690; third-party arithmetic, out of scope): a 3x3 box blur and central
-    differences, negative values clipped to 0 as ddepth = CV_8U does.  What matters here is that
-    they are functions of the image, so the two views' descriptors correspond."""
-    f = img.astype(np.float32)
-    p = np.pad(f, 1, mode="edge")
-    blur = sum(p[dy:dy + f.shape[0], dx:dx + f.shape[1]] for dy in range(3) for dx in range(3)) / 9.0
-    q = np.pad(blur, 1, mode="edge")
-    gx = q[1:-1, 2:] - q[1:-1, :-2]
-    gy = q[2:, 1:-1] - q[:-2, 1:-1]
-    return (np.clip(gx * 4, 0, 255).astype(np.uint8), np.clip(gy * 4, 0, 255).astype(np.uint8))
+_cv8u_gradients = synth.gradient_stand_ins
 
 
 def test_config1_whole_chain_on_the_741x500_stand_in(ctx, oracle):

@@ -573,6 +573,26 @@ def test_match_matches_oracle(ctx, oracle, algo, n1, n2):
         ctx.set_match_algo(api.MATCH_AUTO)
 
 
+@pytest.mark.parametrize("n1,n2", [(171, 210), (5, 17), (300, 9000), (5000, 700), (3, 8193)])
+def test_match_small_problem_kernel(ctx, oracle, n1, n2):
+    """What AUTO picks below the MFMA threshold (match_small_kernel: 16 lanes share a query): both
+    forms -- distances kept in LDS (n2 <= 8192) and recomputed -- against the oracle and against
+    the one-lane-per-query exact scan, with infinities, NaNs and all-equal rows in list2."""
+    d1, s1, d2, s2 = synth.descriptor_sets(n1 + 7 * n2, n1, n2)
+    if n2 > 16:
+        d2[0, 1] = np.inf           # +inf distance at j = 0: the first finite row becomes closest, second = 0
+        d2[3] = d2[2]               # ties: the first wins
+        d2[n2 - 1, 5] = np.nan
+        d1[0] = np.inf              # every distance of query 0 is inf or NaN
+    want = oracle.match(d1, s1, d2, s2, 1000.0)
+    _match_equal(ctx.match(d1, s1, d2, s2, 1000.0), want)
+    ctx.set_match_algo(api.MATCH_EXACT)
+    try:
+        _match_equal(ctx.match(d1, s1, d2, s2, 1000.0), want)
+    finally:
+        ctx.set_match_algo(api.MATCH_AUTO)
+
+
 @pytest.mark.parametrize("algo", ALGOS)
 def test_match_corner_cases(ctx, oracle, algo):
     d1, s1, d2, s2 = synth.descriptor_sets(3, 128, 200)
