@@ -246,7 +246,7 @@ __global__ __launch_bounds__(EXT_THREADS) void disp_ext_bruteforce_kernel(
 
 // LDS ring rows for a window: win + 2 of them are live at once; 16 (a mask instead of a modulo)
 // up to 13x13, 20 for 15x15 (32 rows would not fit the LDS next to 16 waves' img1 columns)
-constexpr int band_ring(int win) { return win + 2 <= 16 ? 16 : 20; }
+constexpr int band_ring(int win) { return win + 2 <= 16 ? 16 : win + 2 <= 20 ? 20 : win + 2; }
 template <int RING> __device__ __forceinline__ int band_slot(int yy) { return (yy + 4 * RING) % RING; }
 constexpr int BAND_ND = 16;          // disparities per wave
 constexpr int BAND_COLS = 256;       // columns per tile (64 lanes x 4)
@@ -359,6 +359,19 @@ __device__ __forceinline__ unsigned from_right(unsigned v)
     return r;
 }
 
+// lane i of a 16-lane row receives lane i-N / i+N of the SAME row (row_shr:N / row_shl:N), zero
+// from beyond the row: one instruction whatever the distance, and folded into the consuming add
+template <int N> __device__ __forceinline__ unsigned row_from_left(unsigned v)
+{
+    static_assert(N >= 1 && N <= 15, "row_shr distance");
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xf, 0xf, true);
+}
+template <int N> __device__ __forceinline__ unsigned row_from_right(unsigned v)
+{
+    static_assert(N >= 1 && N <= 15, "row_shl distance");
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xf, 0xf, true);
+}
+
 struct BandArgs {
     const uint8_t *img0;
     const uint8_t *img1;
@@ -392,7 +405,18 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     // 13x13 and 15x15 (PKW): costs reach 255 * 225 < 2^16, so a key may pass 2^31 and neither the
     // bias nor bit 31 can mark an invalid candidate.  There the mask word saturates the cost field
     // (0xFFFF0000) and a disparity past D carries an all-ones code, both above every valid key.
-    constexpr bool PK = !SSD && R > 0;
+    // WIDE (SAD windows 17x17 .. 31x31): the window reaches up to four lanes to each side, too far
+    // for chained wave_shr:1 hops.  The wave is treated as four independent rows of 16 lanes, each
+    // with its own halo lanes, because inside a row DPP row_shr:N / row_shl:N reach any distance in
+    // one instruction: a row-wide prefix sum of the lanes' four-column totals gives the whole
+    // lanes of a window as a difference of two fetched prefixes, the two partly covered lanes add
+    // a fetched suffix / prefix, and the slide across the lane's four columns fetches one column
+    // each way.  16 - 2 HL of a row's 16 lanes produce output (12, 10 or 8), the others only feed
+    // their neighbours.  Costs reach 255 * 961 < 2^18: plain 32-bit column sums, key = cost << 12 |
+    // code as for the 1x1 window.
+    constexpr bool WIDE = R > 7;
+    static_assert(!(WIDE && SSD), "wide windows: SAD only (an SSD key would need 34 bits)");
+    constexpr bool PK = !SSD && R > 0 && !WIDE;
     constexpr bool PKW = PK && R > 5;
     constexpr unsigned PK_PAST = PKW ? 0u : WIN <= 9 ? 3584u : 3000u;
     constexpr unsigned PK_MASKED = PKW ? 0xFFFF0000u : BAND_MASKED;
@@ -413,9 +437,11 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     constexpr unsigned PAST_D = SSD ? BAND_MASKED : BAND_PAST_D;
     constexpr unsigned INIT = PK ? (((unsigned)(WIN * WIN * 255 + 1) << 16) - 1u)
                                  : SSDW ? SSDW_MASKED : SSD ? 0x7FFFFFFFu : BAND_INIT;
-    constexpr int HL = (R + 3) / 4;  // halo lanes on each side of the tile
-    constexpr int TILE_OUT = BAND_COLS - 8 * HL;
+    constexpr int HL = (R + 3) / 4;  // halo lanes on each side of the tile (WIDE: of each 16-lane row)
+    constexpr int OL = 16 - 2 * HL;  // WIDE: output lanes per row
+    constexpr int TILE_OUT = WIDE ? 16 * OL : BAND_COLS - 8 * HL;
     constexpr int RING = band_ring(WIN);
+    static_assert(!WIDE || ((255ull * WIN * WIN) << BAND_SH) + 4095ull < BAND_INIT, "wide SAD key width");
     static_assert(WIN + 2 <= RING && RING >= 8, "ring too small");
 
     extern __shared__ u32x4 band_lds4[];
@@ -433,18 +459,21 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
+    // this lane's group of four tile columns; WIDE: the rows' column ranges overlap by their halos
+    const int lcg = WIDE ? (lane >> 4) * OL + (lane & 15) : lane;
+    const bool out_lane = !WIDE || ((lane & 15) >= HL && (lane & 15) < 16 - HL);
     const size_t pair = blockIdx.z;
     const uint8_t *i0 = a.img0 + pair * a.pair_stride;
     const uint8_t *i1 = a.img1 + pair * a.pair_stride;
     const int w = a.w, h = a.h;
-    const int x0 = (int)blockIdx.x * TILE_OUT - 4 * HL;  // image column of lane 0, column 0
+    const int x0 = (int)blockIdx.x * TILE_OUT - 4 * HL;  // image column of column group 0, column 0
     const int yb = a.row0 + (int)blockIdx.y * a.bh;      // first output row of the band
     const int yend = min(yb + a.bh, a.row0 + a.rows);    // one past the last output row
     const int dB = a.dbase + BAND_ND * wave;             // this wave's first disparity
     const bool active = dB < a.D;  // waves past the last disparity block only help fill the ring
     const int rbase = x0 - a.dbase - BAND_ND * nw;       // image column of Rrow[.][0]
     // this lane's first img1 word: column x0 + 4*lane - dB - 16
-    const int roff4 = lane + (BAND_ND / 4) * (nw - 1 - wave);
+    const int roff4 = lcg + (BAND_ND / 4) * (nw - 1 - wave);
 
     for (int i = tid; i < 2 * BAND_COLS; i += blockDim.x) best[i] = INIT;
 
@@ -522,7 +551,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     } else {
         bool carrier[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) carrier[c] = ((x0 + 4 * lane + c + 1024 * WIN) % WIN) == 0;
+        for (int c = 0; c < 4; ++c) carrier[c] = ((x0 + 4 * lcg + c + 1024 * WIN) % WIN) == 0;
 #pragma unroll
         for (int dd = 0; dd < BAND_ND; ++dd) {
             const unsigned code = dB + dd < a.D ? LOW - (unsigned)(SSD ? dB + dd - a.dbase : dB + dd)
@@ -545,7 +574,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
         if (active) {
             const int slot = band_slot<RING>(ys);
             unsigned rv[20], lv[4];
-            lds_read_1_5(Lrow4 + slot * (BAND_COLS / 4) + lane, Rrow4 + slot * rw4 + roff4, lv, rv);
+            lds_read_1_5(Lrow4 + slot * (BAND_COLS / 4) + lcg, Rrow4 + slot * rw4 + roff4, lv, rv);
             if constexpr (PK) {
 #pragma unroll
                 for (int pp = 0; pp < BAND_ND / 2; ++pp) {
@@ -594,7 +623,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
         if (active && R > 0 && ys - WIN >= ys0) {
             const int slot = band_slot<RING>(ys - WIN);
             unsigned rv[20], lv[4];
-            lds_read_1_5(Lrow4 + slot * (BAND_COLS / 4) + lane, Rrow4 + slot * rw4 + roff4, lv, rv);
+            lds_read_1_5(Lrow4 + slot * (BAND_COLS / 4) + lcg, Rrow4 + slot * rw4 + roff4, lv, rv);
             if constexpr (PK) {
 #pragma unroll
                 for (int pp = 0; pp < BAND_ND / 2; ++pp) {
@@ -641,6 +670,53 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
                 if (R == 0) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) cost[c] = W1[dd][c];
+                } else if constexpr (WIDE) {
+                    const unsigned t01 = V[dd][0] + V[dd][1], t23 = V[dd][2] + V[dd][3];
+                    unsigned P = t01 + t23;  // inclusive prefix of the lanes' totals along the row
+                    P += row_from_left<1>(P);
+                    P += row_from_left<2>(P);
+                    P += row_from_left<4>(P);
+                    P += row_from_left<8>(P);
+                    // cost[0] covers columns -R .. R of this lane: qL whole lanes and the last remL
+                    // columns of one more to the left; this lane, qR whole lanes and the first remR
+                    // columns of one more to the right
+                    constexpr int qL = R / 4, remL = R % 4, qR = (R - 3) / 4, remR = (R - 3) % 4;
+                    unsigned edge = 0;
+                    if constexpr (remL > 0) {
+                        const unsigned suf = remL == 1 ? V[dd][3] : remL == 2 ? t23 : t23 + V[dd][1];
+                        edge = row_from_left<qL + 1>(suf);
+                    }
+                    if constexpr (remR > 0) {
+                        const unsigned pre = remR == 1 ? V[dd][0] : remR == 2 ? t01 : t01 + V[dd][2];
+                        edge += row_from_right<qR + 1>(pre);
+                    }
+                    unsigned hi = P;
+                    if constexpr (qR > 0) hi = row_from_right<qR>(P);
+                    // (a fetched value is always the MINUEND: see the DPP note in the narrow slide)
+                    unsigned n0 = row_from_left<qL + 1>(P) - hi;  // a prefix from left of the row is 0
+                    asm volatile("" : "+v"(n0));
+                    cost[0] = edge - n0;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        constexpr int unused = 0;
+                        (void)unused;
+                        const int take = c + 1 + R, dropd = R - c;  // columns to the right / left of column 0
+                        unsigned tk, dr;
+                        switch (take / 4) {
+                        case 2: tk = row_from_right<2>(V[dd][take % 4]); break;
+                        case 3: tk = row_from_right<3>(V[dd][take % 4]); break;
+                        default: tk = row_from_right<4>(V[dd][take % 4]); break;
+                        }
+                        const int dcol = (4 - dropd % 4) % 4;
+                        switch ((dropd + 3) / 4) {
+                        case 2: dr = row_from_left<2>(V[dd][dcol]); break;
+                        case 3: dr = row_from_left<3>(V[dd][dcol]); break;
+                        default: dr = row_from_left<4>(V[dd][dcol]); break;
+                        }
+                        unsigned n = dr - cost[c];
+                        asm volatile("" : "+v"(n));
+                        cost[c + 1] = tk - n;
+                    }
                 } else if constexpr (R > 4) {
                     // R = 5..7: the window spans two lanes to each side.  cost[0] = this lane's
                     // and the left lane's four columns, columns 8-R..3 of the lane two to the
@@ -718,9 +794,11 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
                         pend[c] = key;
                 }
             }
-            unsigned *b = best + (y & 1) * BAND_COLS + 4 * lane;
+            unsigned *b = best + (y & 1) * BAND_COLS + 4 * lcg;
+            if (out_lane) {  // (WIDE: a halo lane's columns are another row's output columns)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) atomicMin(b + c, m[c]);
+                for (int c = 0; c < 4; ++c) atomicMin(b + c, m[c]);
+            }
         }
 
         if (ys < ys1) fill_store(ys + 1);
@@ -732,7 +810,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
             unsigned key = best[(y & 1) * BAND_COLS + c];
             best[(y & 1) * BAND_COLS + c] = INIT;
             const int x = x0 + c;
-            if ((c >> 2) >= HL && (c >> 2) < 64 - HL && x < w) {
+            if ((c >> 2) >= HL && (c >> 2) < (WIDE ? HL + 4 * OL : 64 - HL) && x < w) {
                 const size_t pix = (size_t)(y - a.row0) * w + x;
                 unsigned *kp = a.keys ? a.keys + pair * (size_t)a.rows * w + pix : nullptr;
                 bool emit;
@@ -987,9 +1065,15 @@ template <int R, bool SSD>
 int launch_band(stx_ctx *ctx, BandArgs a, int n_pairs, void *keys, size_t keys_bytes)
 {
     constexpr int HL = (R + 3) / 4;
-    constexpr int TILE_OUT = BAND_COLS - 8 * HL;
+    constexpr int TILE_OUT = R > 7 ? 16 * (16 - 2 * HL) : BAND_COLS - 8 * HL;
     const int xt = (a.w + TILE_OUT - 1) / TILE_OUT;
-    const int passD = BAND_ND * BAND_MAX_WAVES;  // disparities per pass
+    // disparities per pass: 16 waves' worth, or 8 where 16 waves' img1 columns would not fit the
+    // LDS next to the ring (31x31: 33 ring rows)
+    constexpr size_t LDS_MAX = 160 * 1024;
+    constexpr int RING_ROWS = band_ring(2 * R + 1);
+    constexpr int NW_MAX = sizeof(unsigned) * ((size_t)RING_ROWS * (BAND_COLS + 2 * (BAND_COLS + BAND_ND * BAND_MAX_WAVES)) + 2 * BAND_COLS) <= LDS_MAX
+                               ? BAND_MAX_WAVES : BAND_MAX_WAVES / 2;
+    const int passD = BAND_ND * NW_MAX;
     const int npass = (a.D + passD - 1) / passD;
     // band height: trade the 2R warm-up rows against filling the CUs evenly
     const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
@@ -1067,7 +1151,8 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
     const int D = max_disp < w ? max_disp : w;  // candidates beyond column 0 do not exist
     const bool ssd = cost_mode == STX_COST_SSD && r > 0;  // a single tap orders candidates as SAD does
     // (the band kernel addresses an image through 32-bit buffer offsets: one image below 2 GiB)
-    if (r <= 7 && D <= 4096 && w < 65536 && !ctx->force_bruteforce && (unsigned long long)stride * (unsigned)h < (1ull << 31)) {
+    const bool band_ok = D <= 4096 && w < 65536 && !ctx->force_bruteforce && (unsigned long long)stride * (unsigned)h < (1ull << 31);
+    if (band_ok && (r <= 7 || (r <= 15 && !ssd))) {
         BandArgs a;
         a.img0 = d_img0; a.img1 = d_img1; a.w = w; a.h = h; a.stride = stride;
         a.pair_stride = pair_stride; a.row0 = row0; a.rows = rows; a.bh = rows; a.D = D;
@@ -1092,7 +1177,15 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
         case 4: return launch_band<4, false>(ctx, a, n_pairs, keys, keys_bytes);
         case 5: return launch_band<5, false>(ctx, a, n_pairs, keys, keys_bytes);
         case 6: return launch_band<6, false>(ctx, a, n_pairs, keys, keys_bytes);
-        default: return launch_band<7, false>(ctx, a, n_pairs, keys, keys_bytes);
+        case 7: return launch_band<7, false>(ctx, a, n_pairs, keys, keys_bytes);
+        case 8: return launch_band<8, false>(ctx, a, n_pairs, keys, keys_bytes);
+        case 9: return launch_band<9, false>(ctx, a, n_pairs, keys, keys_bytes);
+        case 10: return launch_band<10, false>(ctx, a, n_pairs, keys, keys_bytes);
+        case 11: return launch_band<11, false>(ctx, a, n_pairs, keys, keys_bytes);
+        case 12: return launch_band<12, false>(ctx, a, n_pairs, keys, keys_bytes);
+        case 13: return launch_band<13, false>(ctx, a, n_pairs, keys, keys_bytes);
+        case 14: return launch_band<14, false>(ctx, a, n_pairs, keys, keys_bytes);
+        default: return launch_band<15, false>(ctx, a, n_pairs, keys, keys_bytes);
         }
     }
     if (r > 7 && r <= 15 && D <= 65536 && !ctx->force_bruteforce) {
