@@ -68,8 +68,9 @@ extern "C" {
 #define STX_MATCH_MFMA_BF16X1 4 /* same with one bf16 MFMA product and a wider (still rigorous) bound */
 
 /* disparity kernel selector (stx_set_disparity_algo) */
-#define STX_DISP_AUTO 0       /* register sliding-sum kernel (win <= 15), LDS column-sum kernel (win 17..31) */
+#define STX_DISP_AUTO 0       /* register sliding-sum kernel (win <= 31, max_disp <= 4096), else the LDS column-sum kernel */
 #define STX_DISP_BRUTEFORCE 1 /* tap-by-tap kernel for every D1-ext call */
+#define STX_DISP_COLSUM 2     /* LDS column-sum kernel for windows 17x17 .. 31x31 (otherwise as AUTO) */
 
 typedef struct stx_ctx stx_ctx;
 
@@ -220,11 +221,11 @@ int stx_disparity_dev(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_img1
  * loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.  Arguments and
  * results are exactly stx_disparity_dev's.  The one scratch buffer the scan needs -- the
  * per-pixel keys carried between passes when more than 256 disparities are searched (128 with a
- * 31x31 SAD window) -- is a
+ * 31x31 window) -- is a
  * static device array inside the library, so this call never calls hipMalloc / hipFree (nor any
  * allocating library routine).  Limit: a scan of more than 256 disparities may cover at most
  * STX_NOALLOC_MAX_PIXELS pixels (n_pairs * w * h; one 3840x2160 pair fits), else
- * STX_ERR_TOO_LARGE; scans of up to 256 (31x31 SAD: 128) disparities need no scratch and have no such limit.
+ * STX_ERR_TOO_LARGE; scans of up to 256 (31x31: 128) disparities need no scratch and have no such limit.
  * Every call on one GPU shares that GPU's array (32 MiB, held until the process ends): calls
  * that overlap on one GPU -- from any context or stream -- race.  Asynchronous. */
 #define STX_NOALLOC_MAX_PIXELS (1 << 23)

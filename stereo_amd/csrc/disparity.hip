@@ -414,8 +414,11 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     // each way.  16 - 2 HL of a row's 16 lanes produce output (12, 10 or 8), the others only feed
     // their neighbours.  Costs reach 255 * 961 < 2^18: plain 32-bit column sums, key = cost << 12 |
     // code as for the 1x1 window.
+    // SSDX (SSD, wide): a window cost needs 26 bits, so the 32-bit key holds cost << 4 | (15 - dd), the
+    // order among the WAVE's 16 disparities only; the wave's winner is widened to cost << 32 |
+    // (4095 - d) for the 64-bit LDS atomic min across the waves.
     constexpr bool WIDE = R > 7;
-    static_assert(!(WIDE && SSD), "wide windows: SAD only (an SSD key would need 34 bits)");
+    constexpr bool SSDX = SSD && WIDE;
     constexpr bool PK = !SSD && R > 0 && !WIDE;
     constexpr bool PKW = PK && R > 5;
     constexpr unsigned PK_PAST = PKW ? 0u : WIN <= 9 ? 3584u : 3000u;
@@ -426,13 +429,14 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     // key and bit 31 cannot mark an invalid candidate.  As for PKW the mask word saturates the cost
     // field (0xFFFFFF00, OR-ed in: above every valid key, the code bits survive), and a disparity
     // past D gets the same word from a wave-uniform constant folded into the same OR.
-    constexpr bool SSDW = SSD && R > 5;
+    constexpr bool SSDW = SSD && R > 5 && !WIDE;
     constexpr unsigned SSDW_MASKED = 0xFFFFFF00u;
-    static_assert(!SSD || SSDW || (unsigned long long)WIN * WIN * 65025ull * 256ull < (1ull << 31), "SSD key width");
+    static_assert(!SSD || SSDW || SSDX || (unsigned long long)WIN * WIN * 65025ull * 256ull < (1ull << 31), "SSD key width");
+    static_assert(!SSDX || (unsigned long long)WIN * WIN * 65025ull * 16ull + 15ull < (1ull << 30), "wide SSD key width");
     static_assert(!SSDW || (unsigned long long)WIN * WIN * 65025ull * 256ull + 255ull < (unsigned long long)SSDW_MASKED,
                   "wide SSD key width");
-    constexpr unsigned SH = PK ? 16u : SSD ? 8u : BAND_SH;  // key = cost << SH | code
-    constexpr unsigned PSH = PK ? 0u : SSD ? 4u : BAND_SH;  // pixel pre-shift in the ring
+    constexpr unsigned SH = PK ? 16u : SSDX ? 4u : SSD ? 8u : BAND_SH;  // key = cost << SH | code
+    constexpr unsigned PSH = PK ? 0u : SSDX ? 2u : SSD ? 4u : BAND_SH;  // pixel pre-shift in the ring
     constexpr unsigned LOW = (1u << SH) - 1;
     constexpr unsigned PAST_D = SSD ? BAND_MASKED : BAND_PAST_D;
     constexpr unsigned INIT = PK ? (((unsigned)(WIN * WIN * 255 + 1) << 16) - 1u)
@@ -475,7 +479,12 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     // this lane's first img1 word: column x0 + 4*lane - dB - 16
     const int roff4 = lcg + (BAND_ND / 4) * (nw - 1 - wave);
 
-    for (int i = tid; i < 2 * BAND_COLS; i += blockDim.x) best[i] = INIT;
+    unsigned long long *best64 = reinterpret_cast<unsigned long long *>(best);  // SSDX: [2][256] 64-bit keys
+    if constexpr (SSDX) {
+        for (int i = tid; i < 2 * BAND_COLS; i += blockDim.x) best64[i] = ~0ull;
+    } else {
+        for (int i = tid; i < 2 * BAND_COLS; i += blockDim.x) best[i] = INIT;
+    }
 
     // ---- ring fill: one image row -> slot ---------------------------------
     // each thread carries at most FILL_MAX words between its global loads (issued
@@ -554,7 +563,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
         for (int c = 0; c < 4; ++c) carrier[c] = ((x0 + 4 * lcg + c + 1024 * WIN) % WIN) == 0;
 #pragma unroll
         for (int dd = 0; dd < BAND_ND; ++dd) {
-            const unsigned code = dB + dd < a.D ? LOW - (unsigned)(SSD ? dB + dd - a.dbase : dB + dd)
+            const unsigned code = dB + dd < a.D ? LOW - (unsigned)(SSDX ? dd : SSD ? dB + dd - a.dbase : dB + dd)
                                                 : SSDW ? 0u : PAST_D;
 #pragma unroll
             for (int c = 0; c < 4; ++c) V[dd][c] = carrier[c] ? code : 0u;
@@ -795,7 +804,17 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
                 }
             }
             unsigned *b = best + (y & 1) * BAND_COLS + 4 * lcg;
-            if (out_lane) {  // (WIDE: a halo lane's columns are another row's output columns)
+            if constexpr (SSDX) {
+                if (out_lane) {
+                    unsigned long long *b64 = best64 + (y & 1) * BAND_COLS + 4 * lcg;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (m[c] < INIT) {  // the wave's winner: cost and pass-local disparity, widened
+                            const unsigned dloc = (unsigned)(dB - a.dbase) + (LOW - (m[c] & LOW));
+                            atomicMin(b64 + c, ((unsigned long long)(m[c] >> SH) << 32) | (4095u - dloc));
+                        }
+                }
+            } else if (out_lane) {  // (WIDE: a halo lane's columns are another row's output columns)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) atomicMin(b + c, m[c]);
             }
@@ -807,14 +826,32 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
         // ---- write out row y (all waves have contributed) ---------------------
         if (y >= yb && tid < BAND_COLS) {
             const int c = tid;
-            unsigned key = best[(y & 1) * BAND_COLS + c];
-            best[(y & 1) * BAND_COLS + c] = INIT;
+            unsigned key;
+            unsigned long long key64 = ~0ull;
+            if constexpr (SSDX) {
+                key64 = best64[(y & 1) * BAND_COLS + c];
+                best64[(y & 1) * BAND_COLS + c] = ~0ull;
+                // the narrow view the code below shares: any valid key < INIT, the code in the low bits
+                key = key64 == ~0ull ? INIT : 0u;
+            } else {
+                key = best[(y & 1) * BAND_COLS + c];
+                best[(y & 1) * BAND_COLS + c] = INIT;
+            }
             const int x = x0 + c;
             if ((c >> 2) >= HL && (c >> 2) < (WIDE ? HL + 4 * OL : 64 - HL) && x < w) {
                 const size_t pix = (size_t)(y - a.row0) * w + x;
                 unsigned *kp = a.keys ? a.keys + pair * (size_t)a.rows * w + pix : nullptr;
                 bool emit;
-                if (SSD) {
+                if constexpr (SSDX) {
+                    // keys carries the best COST between passes (~0: none yet)
+                    const unsigned cost = (unsigned)(key64 >> 32);
+                    emit = true;
+                    if (kp && !a.first_pass) {
+                        const unsigned old = *kp;
+                        emit = key < INIT && (old == ~0u || cost <= old);
+                    }
+                    if (kp && !a.last_pass && emit) *kp = key < INIT ? cost : ~0u;
+                } else if (SSD) {
                     // the output array carries the best disparity between passes, keys the best key
                     emit = true;
                     if (kp && !a.first_pass) {
@@ -836,6 +873,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
                         v = x;  // no valid candidate: xBest stays 0
                     else
                         v = PK ? (int)(((unsigned)x - key) & LOW)  // the key's code is xBest (mod 2^16)
+                            : SSDX ? (int)(4095u - (unsigned)(key64 & 0xFFFFFFFFu)) + a.dbase
                                : (int)(LOW - (key & LOW)) + (SSD ? a.dbase : 0);  // d = x - xBest
                     uint8_t *orow = a.out + pair * a.out_pair_stride + (size_t)(y - a.row0) * a.out_stride;
                     if (a.out_bytes == 1)
@@ -1071,7 +1109,8 @@ int launch_band(stx_ctx *ctx, BandArgs a, int n_pairs, void *keys, size_t keys_b
     // LDS next to the ring (31x31: 33 ring rows)
     constexpr size_t LDS_MAX = 160 * 1024;
     constexpr int RING_ROWS = band_ring(2 * R + 1);
-    constexpr int NW_MAX = sizeof(unsigned) * ((size_t)RING_ROWS * (BAND_COLS + 2 * (BAND_COLS + BAND_ND * BAND_MAX_WAVES)) + 2 * BAND_COLS) <= LDS_MAX
+    constexpr int BEST_WORDS = (SSD && R > 7 ? 4 : 2) * BAND_COLS;  // wide SSD: 64-bit keys
+    constexpr int NW_MAX = sizeof(unsigned) * ((size_t)RING_ROWS * (BAND_COLS + 2 * (BAND_COLS + BAND_ND * BAND_MAX_WAVES)) + BEST_WORDS) <= LDS_MAX
                                ? BAND_MAX_WAVES : BAND_MAX_WAVES / 2;
     const int passD = BAND_ND * NW_MAX;
     const int npass = (a.D + passD - 1) / passD;
@@ -1112,7 +1151,7 @@ int launch_band(stx_ctx *ctx, BandArgs a, int n_pairs, void *keys, size_t keys_b
         a.first_pass = p == 0;
         a.last_pass = p == npass - 1;
         const int rw = BAND_COLS + BAND_ND * nw;
-        const size_t lds = sizeof(unsigned) * ((size_t)band_ring(2 * R + 1) * (BAND_COLS + 2 * rw) + 2 * BAND_COLS);
+        const size_t lds = sizeof(unsigned) * ((size_t)band_ring(2 * R + 1) * (BAND_COLS + 2 * rw) + BEST_WORDS);
         const int rc = stx_set_lds_attr(ctx, reinterpret_cast<const void *>(disp_band_kernel<R, SSD>), (int)lds);
         if (rc != STX_OK) return rc;
         hipLaunchKernelGGL((disp_band_kernel<R, SSD>), dim3(xt, bands, n_pairs), dim3(64 * nw), lds,
@@ -1152,7 +1191,7 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
     const bool ssd = cost_mode == STX_COST_SSD && r > 0;  // a single tap orders candidates as SAD does
     // (the band kernel addresses an image through 32-bit buffer offsets: one image below 2 GiB)
     const bool band_ok = D <= 4096 && w < 65536 && !ctx->force_bruteforce && (unsigned long long)stride * (unsigned)h < (1ull << 31);
-    if (band_ok && (r <= 7 || (r <= 15 && !ssd))) {
+    if (band_ok && r <= 15 && !(ctx->force_colsum && r > 7)) {
         BandArgs a;
         a.img0 = d_img0; a.img1 = d_img1; a.w = w; a.h = h; a.stride = stride;
         a.pair_stride = pair_stride; a.row0 = row0; a.rows = rows; a.bh = rows; a.D = D;
@@ -1166,7 +1205,15 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
             case 4: return launch_band<4, true>(ctx, a, n_pairs, keys, keys_bytes);
             case 5: return launch_band<5, true>(ctx, a, n_pairs, keys, keys_bytes);
             case 6: return launch_band<6, true>(ctx, a, n_pairs, keys, keys_bytes);
-            default: return launch_band<7, true>(ctx, a, n_pairs, keys, keys_bytes);
+            case 7: return launch_band<7, true>(ctx, a, n_pairs, keys, keys_bytes);
+            case 8: return launch_band<8, true>(ctx, a, n_pairs, keys, keys_bytes);
+            case 9: return launch_band<9, true>(ctx, a, n_pairs, keys, keys_bytes);
+            case 10: return launch_band<10, true>(ctx, a, n_pairs, keys, keys_bytes);
+            case 11: return launch_band<11, true>(ctx, a, n_pairs, keys, keys_bytes);
+            case 12: return launch_band<12, true>(ctx, a, n_pairs, keys, keys_bytes);
+            case 13: return launch_band<13, true>(ctx, a, n_pairs, keys, keys_bytes);
+            case 14: return launch_band<14, true>(ctx, a, n_pairs, keys, keys_bytes);
+            default: return launch_band<15, true>(ctx, a, n_pairs, keys, keys_bytes);
             }
         }
         switch (r) {

@@ -105,8 +105,9 @@ extern "C" int stx_set_match_algo(stx_ctx *ctx, int algo)
 extern "C" int stx_set_disparity_algo(stx_ctx *ctx, int algo)
 {
     if (!ctx) return STX_ERR_INVALID_ARG;
-    if (algo != STX_DISP_AUTO && algo != STX_DISP_BRUTEFORCE) return STX_ERR_INVALID_ARG;
+    if (algo != STX_DISP_AUTO && algo != STX_DISP_BRUTEFORCE && algo != STX_DISP_COLSUM) return STX_ERR_INVALID_ARG;
     ctx->force_bruteforce = algo == STX_DISP_BRUTEFORCE;
+    ctx->force_colsum = algo == STX_DISP_COLSUM;
     return STX_OK;
 }
 

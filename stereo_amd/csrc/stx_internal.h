@@ -40,6 +40,7 @@ struct stx_ctx {
     hipStream_t stream;
     int match_algo;
     int force_bruteforce;  // tests: route every D1-ext call to the tap-by-tap kernel
+    int force_colsum;      // tests: windows 17..31 through the column-sum kernel
     int num_cus;
     void *slot_ptr[STX_SLOT_COUNT];
     size_t slot_bytes[STX_SLOT_COUNT];

@@ -143,32 +143,52 @@ def test_disparity_ssd_extreme_contrast(ctx, oracle):
         assert (got == want).all(), (win, cm, np.argwhere(got != want)[:10])
 
 
+@pytest.mark.parametrize("cm", [api.COST_SAD, api.COST_SSD])
 @pytest.mark.parametrize("win", [17, 19, 21, 23, 25, 27, 29, 31])
 @pytest.mark.parametrize("h,w,D", [(45, 777, 256), (37, 400, 130), (24, 1300, 520)])
-def test_disparity_wide_sad_windows_every_radius(ctx, oracle, win, h, w, D):
-    """SAD 17x17 .. 31x31 run the register kernel with the wave cut into four 16-lane rows (row_shr /
-    row_shl DPP): every radius has its own fetch distances, so every radius is checked -- several
-    128/160/192-column tiles, row bands, partial disparity blocks, two and three passes (31x31
-    searches 128 disparities per pass), u16 output."""
-    a, b = _rand_pair(win * 7 + h + w + D, h, w, zero=0.03)
+def test_disparity_wide_windows_every_radius(ctx, oracle, win, h, w, D, cm):
+    """17x17 .. 31x31 run the register kernel with the wave cut into four 16-lane rows (row_shr /
+    row_shl DPP): every radius has its own fetch distances, so every radius is checked, SAD and SSD
+    (64-bit keys across the waves) -- several 128/160/192-column tiles, row bands, partial
+    disparity blocks, two to five passes (31x31 searches 128 disparities per pass), u16 output."""
+    a, b = _rand_pair(win * 7 + h + w + D + cm, h, w, zero=0.03)
     dt = np.uint16 if D > 256 else np.uint8
-    want = oracle.disparity_ext(a, b, win, D, 0, dt, sliding=True)
-    got = ctx.disparity(a, b, win=win, max_disp=D, out_dtype=dt)
+    want = oracle.disparity_ext(a, b, win, D, cm, dt, sliding=True)
+    got = ctx.disparity(a, b, win=win, max_disp=D, cost_mode=cm, out_dtype=dt)
     assert (got == want).all(), np.argwhere(got != want)[:10]
 
 
+@pytest.mark.parametrize("cm", [api.COST_SAD, api.COST_SSD])
+@pytest.mark.parametrize("win", [17, 23, 31])
+@pytest.mark.parametrize("h,w,D", [(40, 300, 16), (50, 777, 256), (36, 700, 300), (1, 65, 5), (33, 129, 700)])
+def test_disparity_column_sum_kernel_forced(ctx, oracle, win, h, w, D, cm):
+    """The LDS column-sum kernel (what windows 17x17 .. 31x31 fall to beyond 4096 disparities or 65535
+    columns), selected with STX_DISP_COLSUM."""
+    a, b = _rand_pair(win * 11 + h + w + D + cm, h, w, zero=0.03)
+    dt = np.uint16 if D > 256 else np.uint8
+    want = oracle.disparity_ext(a, b, win, D, cm, dt, sliding=True)
+    ctx.set_disparity_algo(api.DISP_COLSUM)
+    try:
+        got = ctx.disparity(a, b, win=win, max_disp=D, cost_mode=cm, out_dtype=dt)
+    finally:
+        ctx.set_disparity_algo(api.DISP_AUTO)
+    assert (got == want).all(), np.argwhere(got != want)[:10]
+
+
+@pytest.mark.parametrize("cm", [api.COST_SAD, api.COST_SSD])
 @pytest.mark.parametrize("win", [17, 31])
-def test_disparity_wide_sad_extreme_contrast(ctx, oracle, win):
-    """Costs at the top of the key's cost field (254 or 255 per tap over the whole window) and ties
-    everywhere: the lowest x1 must win."""
+def test_disparity_wide_windows_extreme_contrast(ctx, oracle, win, cm):
+    """Costs at the top of the key's cost field (254 or 255 per tap over the whole window: 26 bits
+    for SSD) and ties everywhere: the lowest x1 must win, also across waves and passes."""
     h, w, D = 40, 300, 200
     a = np.full((h, w), 255, np.uint8)
     b = np.full((h, w), 1, np.uint8)
     b[:, ::7] = 2
     a[5, 9] = 0
     b[7, 100:130] = 0
-    want = oracle.disparity_ext(a, b, win, D, 0, np.uint8, sliding=True)
-    got = ctx.disparity(a, b, win=win, max_disp=D)
+    b[20:24, 150:] = 0
+    want = oracle.disparity_ext(a, b, win, D, cm, np.uint8, sliding=True)
+    got = ctx.disparity(a, b, win=win, max_disp=D, cost_mode=cm)
     assert (got == want).all(), np.argwhere(got != want)[:10]
 
 
@@ -177,8 +197,8 @@ def test_disparity_wide_sad_extreme_contrast(ctx, oracle, win):
 @pytest.mark.parametrize("h,w,D", [(40, 300, 16), (90, 200, 100), (50, 777, 256), (36, 700, 300), (1, 65, 5),
                                    (70, 64, 64), (33, 129, 700)])
 def test_disparity_large_windows_column_sum_kernel(ctx, oracle, win, h, w, D, cm):
-    """Windows 17x17 .. 31x31 (SSD: the LDS column-sum kernel; SAD: the register kernel's wide
-    form, with D > 4096 or forced also the column-sum kernel): several tiles and row bands,
+    """Windows 17x17 .. 31x31 (the register kernel's wide form; the LDS column-sum kernel behind it
+    serves D > 4096 and is checked in test_disparity_column_sum_kernel_forced): several tiles and row bands,
     images smaller than the window, D not a multiple of anything, several 256-disparity passes
     merged through the per-pixel cost buffer (D = 300, 700), SAD and SSD; against the sliding
     oracle (itself checked against the tap-by-tap oracle in tests/test_oracle_kat.py) and, for
