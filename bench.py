@@ -356,9 +356,11 @@ def main():
             "ms": ms, "Mpix_disp_per_s": units / (ms * 1e-3) / 1e6,
             "roofline": valu_roofline(counters, "disp_band_9x9_ssd_d256_2880x1988", units, OPS_PER_UNIT_WINDOWED, ms),
         }
-        # larger windows through the same sliding-sum kernel (two halo lanes per side)
+        # larger windows through the same sliding-sum kernel (two halo lanes per side up to 15x15; beyond
+        # that the wave works as four 16-lane rows with row-DPP fetches)
         for wl, cm, nm in ((11, api.COST_SAD, "sad"), (13, api.COST_SAD, "sad"), (15, api.COST_SAD, "sad"),
-                           (13, api.COST_SSD, "ssd"), (15, api.COST_SSD, "ssd"), (21, api.COST_SAD, "sad")):
+                           (13, api.COST_SSD, "ssd"), (15, api.COST_SSD, "ssd"), (21, api.COST_SAD, "sad"),
+                           (31, api.COST_SAD, "sad"), (31, api.COST_SSD, "ssd")):
             ms = event_time_ms(torch, lambda: ctx.disparity_dev(d_l, d_r, d_o, win=wl, max_disp=D, cost_mode=cm), 3, 1)
             extra["disparity_%s_%dx%d_d256" % (nm, wl, wl)] = {
                 "workload": "%dx%d, %dx%d %s window, %d disparities" % (W, H, wl, wl, nm.upper(), D),
