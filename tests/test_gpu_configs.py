@@ -121,6 +121,34 @@ def test_config4_real_launch_1024_pairs(ctx, oracle):
             assert (sg[k][y0:y0 + 4] == want[y0 - b0:y0 - b0 + 4]).all()
 
 
+@pytest.mark.parametrize("win,cm", [(21, api.COST_SAD), (31, api.COST_SSD)])
+def test_config2_size_wide_windows_two_gpu_kernels_agree(ctx, oracle, win, cm):
+    """BASELINE config 2's pair (2880x1988, 256 disparities) with a wide window: the register kernel's
+    wide form and the LDS column-sum kernel -- two independent implementations -- give the same map
+    over the whole image, and the oracle agrees on three row bands."""
+    import torch
+    h, w, D = 1988, 2880, 256
+    l, r = synth.rectified_pair(2024, h, w, D)
+    a, b = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
+    wide, colsum = torch.empty_like(a), torch.empty_like(a)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.disparity_dev(a, b, wide, win=win, max_disp=D, cost_mode=cm)
+        ctx.set_disparity_algo(api.DISP_COLSUM)
+        ctx.disparity_dev(a, b, colsum, win=win, max_disp=D, cost_mode=cm)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_disparity_algo(api.DISP_AUTO)
+        ctx.set_stream(0)
+    assert bool((wide == colsum).all().item())
+    g = wide.cpu().numpy()
+    rr = win // 2
+    for y0 in (0, 997, h - 3):
+        b0, b1 = max(0, y0 - rr), min(h, y0 + 3 + rr)
+        want = oracle.disparity_ext(l[b0:b1], r[b0:b1], win, D, cm, sliding=True)
+        assert (g[y0:y0 + 3] == want[y0 - b0:y0 - b0 + 3]).all()
+
+
 # ------------------------------------------------------------------ config 1 ----
 
 _cv8u_gradients = synth.gradient_stand_ins
