@@ -26,14 +26,18 @@ def best(f, reps=12):
 def one():
     ctx.match_dev(t[0], t[1], t[2], t[3], 1000.0, *outs)
 
-def four():
-    qc = 50_176
+def chunks(qc):
     for q0 in range(0, n, qc):
         q1 = min(n, q0 + qc)
         ctx.match_dev(t[0][q0:q1], t[1][q0:q1], t[2], t[3], 1000.0, *[o[q0:q1] for o in outs])
 
-for _ in range(3): one(); four()
+four = lambda: chunks(50_176)
+two = lambda: chunks(100_352)
+three = lambda: chunks(67_072)
+for _ in range(3): one(); four(); two(); three()
 print("device, one launch:        best %.2f median %.2f ms" % best(one))
+print("device, two query chunks:  best %.2f median %.2f ms" % best(two))
+print("device, three query chunks: best %.2f median %.2f ms" % best(three))
 print("device, four query chunks: best %.2f median %.2f ms" % best(four))
 for _ in range(3): ctx.match(d1, s1, d2, s2, 1000.0)
 print("host, pageable arrays:     best %.2f median %.2f ms" % best(lambda: ctx.match(d1, s1, d2, s2, 1000.0)))
