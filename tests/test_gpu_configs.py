@@ -348,6 +348,9 @@ def test_host_pipeline_equals_plain_copies(ctx, oracle, threads, chunks):
         dz = np.zeros((h + 7, w - 9), np.uint8)
         ctx.rectify(src, dz, Hinv, api.RECT_DST_IS_ZERO)
         res.append(dz)
+        dzs = np.full((h, w + 40), 9, np.uint8)     # pitched destination: the pad bytes must survive
+        ctx.rectify(src, dzs[:, :w], Hinv, api.RECT_DST_IS_ZERO)
+        res.append(dzs)
         res.extend(ctx.rectify_disparity(l, r, Hinv, Hinv, win=7, max_disp=32, want_rectified=True))
         res.append(ctx.rectify_disparity(l, r, Hinv, Hinv))
         res.extend(ctx.match(d1, s1, d2, s2, 1000.0))
