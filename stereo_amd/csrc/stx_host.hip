@@ -9,6 +9,9 @@
 // ctx->host_pipeline == 0 (stx_set_host_pipeline, or STX_HOST_PIPELINE=0 in the environment)
 // selects plain hipMemcpyAsync calls on the caller's buffers instead, for A/B measurements.
 #include <atomic>
+#if defined(__x86_64__)
+#include <emmintrin.h>
+#endif
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -36,15 +39,56 @@ struct stx_host_pool {
     size_t spitch = 0, dpitch = 0, wbytes = 0, rows = 0;
 };
 
+// memcpy for the large staging copies: non-temporal 16-byte stores (SSE2, baseline x86-64), a
+// whole cache line per iteration.  An ordinary store first reads the destination line into the
+// cache (read for ownership), so a plain copy moves three bytes over the memory bus per byte
+// copied; the staging buffers are written once and then read by the DMA engines (uploads) or
+// the caller much later (downloads), never by this core again.  STX_HOST_NT_COPY=0 in the
+// environment selects plain memcpy (A/B measurements).
+#if defined(__x86_64__)
+static bool nt_copy_on()
+{
+    static const int on = [] {
+        const char *e = getenv("STX_HOST_NT_COPY");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    return on != 0;
+}
+static void copy_bytes(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    if (n < ((size_t)32 << 10) || !nt_copy_on()) {
+        memcpy(dst, src, n);
+        return;
+    }
+    const size_t head = (64 - ((uintptr_t)dst & 63)) & 63;  // up to the destination's next cache line
+    memcpy(dst, src, head);
+    dst += head; src += head; n -= head;
+    const size_t lines = n / 64;
+    for (size_t i = 0; i < lines; ++i) {
+        const __m128i a = _mm_loadu_si128((const __m128i *)(src) + 0), b = _mm_loadu_si128((const __m128i *)(src) + 1),
+                      c = _mm_loadu_si128((const __m128i *)(src) + 2), d = _mm_loadu_si128((const __m128i *)(src) + 3);
+        _mm_stream_si128((__m128i *)(dst) + 0, a);
+        _mm_stream_si128((__m128i *)(dst) + 1, b);
+        _mm_stream_si128((__m128i *)(dst) + 2, c);
+        _mm_stream_si128((__m128i *)(dst) + 3, d);
+        src += 64; dst += 64;
+    }
+    _mm_sfence();  // the streamed lines are globally visible before the DMA / the pool's release
+    memcpy(dst, src, n - lines * 64);
+}
+#else
+static void copy_bytes(uint8_t *dst, const uint8_t *src, size_t n) { memcpy(dst, src, n); }
+#endif
+
 static void copy_rows(uint8_t *dst, size_t dpitch, const uint8_t *src, size_t spitch, size_t wbytes, size_t r0,
                       size_t r1)
 {
     if (r1 <= r0) return;
     if (dpitch == wbytes && spitch == wbytes) {
-        memcpy(dst + r0 * wbytes, src + r0 * wbytes, (r1 - r0) * wbytes);
+        copy_bytes(dst + r0 * wbytes, src + r0 * wbytes, (r1 - r0) * wbytes);
         return;
     }
-    for (size_t r = r0; r < r1; ++r) memcpy(dst + r * dpitch, src + r * spitch, wbytes);
+    for (size_t r = r0; r < r1; ++r) copy_bytes(dst + r * dpitch, src + r * spitch, wbytes);
 }
 
 static inline void cpu_relax()
@@ -627,7 +671,7 @@ int stx_host_upload_flat(stx_ctx *ctx, void *d_dst, const void *src, size_t byte
         // rows of 64 KiB so that the workers share one chunk
         const size_t rowb = (size_t)64 << 10, rows = n / rowb, tail = n - rows * rowb;
         if (rows) pool_copy2d(ctx, pin + off, rowb, (const uint8_t *)src + off, rowb, rowb, rows);
-        if (tail) memcpy(pin + off + rows * rowb, (const uint8_t *)src + off + rows * rowb, tail);
+        if (tail) copy_bytes(pin + off + rows * rowb, (const uint8_t *)src + off + rows * rowb, tail);
         STX_HIP(hipMemcpyAsync((uint8_t *)d_dst + off, pin + off, n, hipMemcpyHostToDevice, ctx->s_in));
     }
     STX_HIP(hipEventRecord(ctx->ev_in[0], ctx->s_in));
