@@ -61,7 +61,7 @@ extern "C" {
                                    misses are written as 0 and dst is never read */
 
 /* matching algorithm selector (stx_set_match_algo) */
-#define STX_MATCH_AUTO 0  /* exact scan for small problems, bf16 MFMA prefilter otherwise */
+#define STX_MATCH_AUTO 0  /* exact scan, 16 lanes per query, for small problems; bf16 MFMA prefilter + exact replay otherwise */
 #define STX_MATCH_EXACT 1 /* VALU scan in reference operation order */
 #define STX_MATCH_MFMA 2  /* fp32 MFMA prefilter + exact replay of the running-minimum records */
 #define STX_MATCH_MFMA_BF16 3 /* same with the dot products as 3 bf16 MFMA products (hi/lo split) */
