@@ -402,6 +402,14 @@ int stx_match_multi(stx_multi *m, const float *desc1, const float *score1, int n
                     const float *score2, int n2, float dist_limit, int32_t *closest, int32_t *second,
                     float *min_dist, float *second_dist, uint8_t *status);
 
+/* RectifyImage's loop (Stereography.cpp:612-630) for ONE image over the handle's devices
+ * (SURVEY 8e, row R): every device holds a copy of the source and fills a contiguous band of
+ * destination rows; the warp is output-pixel-local, so there is no halo and no exchange.
+ * Arguments as stx_rectify_u8.  Host pointers; blocking. */
+int stx_rectify_multi_u8(stx_multi *m, const uint8_t *src, int src_w, int src_h, size_t src_stride,
+                         uint8_t *dst, int dst_w, int dst_h, size_t dst_stride, const float Hinv[9],
+                         int flags);
+
 #ifdef __cplusplus
 }
 #endif

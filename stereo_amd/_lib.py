@@ -67,6 +67,8 @@ PROTOTYPES = {
     "stx_invert_homography": (C.c_int, [_f32p, _f32p]),
     "stx_rectify_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_int,
                                  C.c_int, C.c_size_t, _f32p, C.c_int]),
+    "stx_rectify_multi_u8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_int,
+                                       C.c_int, C.c_size_t, _f32p, C.c_int]),
     "stx_rectify_u8_keep": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_int,
                                       C.c_int, C.c_size_t, _f32p, C.c_int]),
     "stx_disparity_resident_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -541,6 +541,19 @@ class MultiContext:
                  max(w, 1) * out_dtype.itemsize), "stx_disparity_rowband")
         return out
 
+    def rectify(self, original, rectified, Hinv, flags=RECT_PRESERVE_DST):
+        """As Context.rectify, destination row bands over the devices (every device holds the source)."""
+        _check_image(original, "original")
+        _check_image(rectified, "rectified", writable=True)
+        Hinv = np.ascontiguousarray(Hinv, np.float32).reshape(9)
+        check(self._lib.stx_rectify_multi_u8(
+            self._h, _ptr(original), original.shape[1], original.shape[0],
+            original.strides[0] if original.shape[0] > 1 else max(original.shape[1], 1),
+            _ptr(rectified), rectified.shape[1], rectified.shape[0],
+            rectified.strides[0] if rectified.shape[0] > 1 else max(rectified.shape[1], 1),
+            Hinv.ctypes.data_as(C.POINTER(C.c_float)), int(flags)), "stx_rectify_multi_u8")
+        return rectified
+
     def match(self, desc1, score1, desc2, score2, dist_limit=MAX_DIST_BETWEEN_MATCHES):
         """As Context.match, list1's queries sharded over the devices."""
         desc1 = np.ascontiguousarray(desc1, np.float32).reshape(-1, DESC_LENGTH)

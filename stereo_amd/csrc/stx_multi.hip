@@ -4,6 +4,7 @@
 //   batch of pairs     -> contiguous shares of whole pairs            (stx_disparity_batch_u8)
 //   one large pair     -> row bands + win/2 halo rows per device       (stx_disparity_rowband_*)
 //   matching           -> list1's queries sharded, list2 replicated    (stx_match_multi)
+//   one warp           -> destination row bands, source replicated     (stx_rectify_multi_u8)
 // Inputs and outputs are host buffers: every device uploads exactly the rows it needs from the
 // caller's memory and writes its share of the result straight back to the caller's output, so
 // there is no device-to-device step to pay for (the one-process-per-GPU form with an RCCL
@@ -217,5 +218,42 @@ extern "C" int stx_match_multi(stx_multi *m, const float *desc1, const float *sc
                          dist_limit, closest ? closest + lo : nullptr, second ? second + lo : nullptr,
                          min_dist ? min_dist + lo : nullptr, second_dist ? second_dist + lo : nullptr,
                          status ? status + lo : nullptr);
+    });
+}
+
+extern "C" int stx_rectify_multi_u8(stx_multi *m, const uint8_t *src, int src_w, int src_h, size_t src_stride,
+                                    uint8_t *dst, int dst_w, int dst_h, size_t dst_stride, const float Hinv[9],
+                                    int flags)
+{
+    if (!m || !Hinv || src_w < 0 || src_h < 0 || dst_w < 0 || dst_h < 0) return STX_ERR_INVALID_ARG;
+    if (flags != STX_RECT_PRESERVE_DST && flags != STX_RECT_DST_IS_ZERO) return STX_ERR_INVALID_ARG;
+    if (src_w > 0 && src_h > 0 && (!src || src_stride < (size_t)src_w)) return STX_ERR_INVALID_ARG;
+    if (dst_w > 0 && dst_h > 0 && (!dst || dst_stride < (size_t)dst_w)) return STX_ERR_INVALID_ARG;
+    if (dst_w == 0 || dst_h == 0) return STX_OK;
+    return for_each_device(m, [=](int k) -> int {
+        int lo, hi;
+        share(dst_h, k, m->n, &lo, &hi);
+        if (hi <= lo) return STX_OK;
+        stx_ctx *ctx = m->ctx[k];
+        STX_ENTER(ctx);
+        // the warp is output-pixel-local: this device fills destination rows [lo, hi) from its own
+        // copy of the whole source; no halo, no exchange
+        int err;
+        hipStream_t s = ctx->stream;
+        const size_t sp = (size_t)(src_w > 0 ? src_w : 1), dp = (size_t)dst_w;
+        const size_t rows = (size_t)(hi - lo);
+        uint8_t *dsrc = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG0, sp * (size_t)(src_h > 0 ? src_h : 1), &err);
+        if (!dsrc) return err;
+        uint8_t *ddst = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG1, dp * rows, &err);
+        if (!ddst) return err;
+        if (src_w > 0 && src_h > 0)
+            STX_HIP(hipMemcpy2DAsync(dsrc, sp, src, src_stride, (size_t)src_w, (size_t)src_h, hipMemcpyHostToDevice, s));
+        uint8_t *band = dst + (size_t)lo * dst_stride;
+        if (flags == STX_RECT_PRESERVE_DST)
+            STX_HIP(hipMemcpy2DAsync(ddst, dp, band, dst_stride, dp, rows, hipMemcpyHostToDevice, s));
+        int r = stx_rectify_rowband_u8_dev(ctx, dsrc, src_w, src_h, sp, ddst, dst_w, lo, hi - lo, dp, Hinv, flags);
+        if (r) return r;
+        STX_HIP(hipMemcpy2DAsync(band, dst_stride, ddst, dp, dp, rows, hipMemcpyDeviceToHost, s));
+        return (int)hipStreamSynchronize(s);
     });
 }

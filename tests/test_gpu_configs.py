@@ -538,6 +538,11 @@ def test_multi_device_handle_matches_single_calls(ctx, oracle):
     want_w16 = ctx.disparity(big_l, big_r, win=9, max_disp=300, out_dtype=np.uint16)
     want_ssd = ctx.disparity(big_l, big_r, win=5, max_disp=32, cost_mode=api.COST_SSD)
     want_m = ctx.match(d1, s1, d2, s2, 1000.0)
+    src = synth.texture(61, 301, 900)
+    Hinv = oracle.invert3x3(synth.homography(7, 900, 301))
+    seed_dst = np.random.RandomState(4).randint(0, 255, (310, 880)).astype(np.uint8)
+    want_r = oracle.rectify(src, seed_dst.copy(), Hinv)
+    want_rz = oracle.rectify(src, np.zeros((310, 880), np.uint8), Hinv)
     for n in _device_counts():
         m = MultiContext(list(range(n)))
         try:
@@ -552,6 +557,10 @@ def test_multi_device_handle_matches_single_calls(ctx, oracle):
                     == ctx.disparity(big_l[:3], big_r[:3], win=9, max_disp=16)).all()
             _match_equal(m.match(d1, s1, d2, s2, 1000.0), want_m)
             _match_equal(m.match(d1[:1], s1[:1], d2, s2, 1000.0), [x[:1] for x in want_m])
+            assert (m.rectify(src, seed_dst.copy(), Hinv) == want_r).all()          # misses keep the destination
+            padded = np.full((310, 900), 5, np.uint8)
+            m.rectify(src, padded[:, :880], Hinv, api.RECT_DST_IS_ZERO)
+            assert (padded[:, :880] == want_rz).all() and (padded[:, 880:] == 5).all()
         finally:
             m.close()
 
