@@ -352,6 +352,15 @@ int main()
             if (stx_disparity_rowband_u8(m, a.data(), b.data(), w, h, w, 1, 0, STX_COST_SAD, got.data(), w) != STX_OK) ++fails;
             oracle_disparity_ref(a.data(), b.data(), w, h, w, want.data(), w);
             if (std::memcmp(want.data(), got.data(), want.size()) != 0) ++fails;
+            {   // one warp over the handle's devices
+                const float hm[9] = {1.01f, 0.02f, -3.f, -0.015f, 0.99f, 2.5f, 1e-5f, -2e-5f, 1.f};
+                float hinv[9];
+                oracle_invert3x3(hm, hinv);
+                std::vector<uint8_t> wr((size_t)w * h, 0), gr((size_t)w * h, 0);
+                oracle_rectify(a.data(), w, h, w, wr.data(), w, h, w, hinv);
+                if (stx_rectify_multi_u8(m, a.data(), w, h, w, gr.data(), w, h, w, hinv, STX_RECT_DST_IS_ZERO) != STX_OK) ++fails;
+                if (std::memcmp(wr.data(), gr.data(), wr.size()) != 0) ++fails;
+            }
             stx_multi_destroy(m);
         }
         std::printf("multi-device fails so far: %d (%d device(s) visible)\n", fails, nd);
