@@ -413,6 +413,11 @@ int stx_disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, i
         // whose windows end inside what has been uploaded so far
         int up_prev = 0, out_prev = 0;  // band-relative input rows uploaded / output rows computed
         int out_lo[STX_HOST_MAX_CHUNKS], out_n[STX_HOST_MAX_CHUNKS];
+        // A small map (up to 4 MB: 1080p, not config 2's 5.7 MB) is stored by the scan straight into
+        // page-locked host memory, as the warp's destination is: no download to set up and wait for
+        // (741x500: 0.165 -> 0.134 ms, 1080p: 0.29 -> 0.27 ms; at 5.7 MB the chunked download is as fast).
+        const bool zc = oimg <= ((size_t)4 << 20) && stx_host_zero_copy_on();
+        uint8_t *ktarget = zc ? (out_direct ? o : pin_out) : dout;
         for (int c = 0; c < nc; ++c) {
             const int up_next = c == nc - 1 ? bh : (int)((long long)bh * (c + 1) / nc);
             const size_t ro = (size_t)up_prev * p, rn = (size_t)(up_next - up_prev);
@@ -433,15 +438,26 @@ int stx_disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, i
             STX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_in[c], 0));
             if (out_n[c] > 0) {
                 rc = stx_launch_disparity(ctx, d0, d1, 1, w, bh, p, 0, row0 - b0 + out_prev, out_n[c], win,
-                                          max_disp, cost_mode, dout + (size_t)out_prev * op, op, 0, out_bytes);
+                                          max_disp, cost_mode, ktarget + (size_t)out_prev * op, op, 0, out_bytes);
                 if (rc) return rc;
             }
             STX_HIP(hipEventRecord(ctx->ev_k[c], ctx->stream));
-            rc = stx_host_download_begin(ctx, out_direct ? o + (size_t)out_prev * op : pin_out + (size_t)out_prev * op,
-                                         dout + (size_t)out_prev * op, (size_t)out_n[c] * op, ctx->ev_k[c],
-                                         ctx->ev_out[c]);
-            if (rc) return rc;
+            if (!zc) {
+                rc = stx_host_download_begin(ctx, out_direct ? o + (size_t)out_prev * op : pin_out + (size_t)out_prev * op,
+                                             dout + (size_t)out_prev * op, (size_t)out_n[c] * op, ctx->ev_k[c],
+                                             ctx->ev_out[c]);
+                if (rc) return rc;
+            }
             out_prev = out_next;
+        }
+        if (zc) {
+            for (int c = 0; c < nc; ++c) {
+                STX_HIP(hipEventSynchronize(ctx->ev_k[c]));
+                if (!out_direct && out_n[c] > 0)
+                    pool_copy2d(ctx, o + (size_t)out_lo[c] * out_stride, out_stride, pin_out + (size_t)out_lo[c] * op, op, op,
+                                (size_t)out_n[c]);
+            }
+            return STX_OK;
         }
         for (int c = 0; c < nc; ++c) {
             rc = stx_host_download_end(ctx, o + (size_t)out_lo[c] * out_stride, out_stride,
