@@ -656,8 +656,10 @@ extern "C" int stx_rectify_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const
     rc = stx_rectify_u8_dev(ctx, dsrc, w, h, p, img, drect, w, h, p, img, hinv, 2, STX_RECT_DST_IS_ZERO);
     if (rc) return rc;
     if (pipe) STX_HIP(hipEventRecord(ctx->ev_k[1], s));  // the rectified images may leave while the scan runs
-    rc = stx_launch_disparity(ctx, drect, drect + img, 1, w, h, p, 0, 0, h, win, max_disp, cost_mode, dout, p,
-                              0, 1);
+    // a small map is stored by the scan straight into the pinned buffer (as stx_disparity_u8 does)
+    const bool zc = pipe && img <= ((size_t)4 << 20) && stx_host_zero_copy_on();
+    rc = stx_launch_disparity(ctx, drect, drect + img, 1, w, h, p, 0, 0, h, win, max_disp, cost_mode,
+                              zc ? (uint8_t *)ctx->pin_ptr[1] : dout, p, 0, 1);
     if (rc) return rc;
     if (pipe) {
         uint8_t *pin_out = (uint8_t *)ctx->pin_ptr[1];
@@ -672,8 +674,10 @@ extern "C" int stx_rectify_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const
             rc = stx_host_download_begin(ctx, pin_out + (size_t)s1 * img, drect + img, img, ctx->ev_k[1], ctx->ev_out[s1]);
             if (rc) return rc;
         }
-        rc = stx_host_download_begin(ctx, pin_out, dout, img, ctx->ev_k[0], ctx->ev_out[0]);
-        if (rc) return rc;
+        if (!zc) {
+            rc = stx_host_download_begin(ctx, pin_out, dout, img, ctx->ev_k[0], ctx->ev_out[0]);
+            if (rc) return rc;
+        }
         if (rect0) {
             rc = stx_host_download_end(ctx, rect0, rect_stride, pin_out + (size_t)s0 * img, p, (size_t)h, ctx->ev_out[s0]);
             if (rc) return rc;
@@ -682,7 +686,7 @@ extern "C" int stx_rectify_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const
             rc = stx_host_download_end(ctx, rect1, rect_stride, pin_out + (size_t)s1 * img, p, (size_t)h, ctx->ev_out[s1]);
             if (rc) return rc;
         }
-        return stx_host_download_end(ctx, out, out_stride, pin_out, p, (size_t)h, ctx->ev_out[0]);
+        return stx_host_download_end(ctx, out, out_stride, pin_out, p, (size_t)h, zc ? ctx->ev_k[0] : ctx->ev_out[0]);
     }
     STX_HIP(copy_image_d2h(out, out_stride, dout, p, (size_t)w, (size_t)h, s));
     if (rect0) STX_HIP(copy_image_d2h(rect0, rect_stride, drect, p, (size_t)w, (size_t)h, s));

@@ -222,7 +222,7 @@ bool stx_host_pipeline_on(stx_ctx *ctx)
 }
 
 // STX_HOST_ZERO_COPY=0 in the environment: kernels never write host memory directly (A/B measurements)
-static bool stx_host_zero_copy_on()
+bool stx_host_zero_copy_on()
 {
     static const int on = [] {
         const char *e = getenv("STX_HOST_ZERO_COPY");

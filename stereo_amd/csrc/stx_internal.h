@@ -101,6 +101,7 @@ int stx_set_lds_attr(stx_ctx *ctx, const void *fn, int lds);
 void stx_host_release(stx_ctx *ctx);
 bool stx_host_pipeline_on(stx_ctx *ctx);
 int stx_host_prepare(stx_ctx *ctx, size_t in_bytes, size_t out_bytes);
+bool stx_host_zero_copy_on();  // kernels may store small results straight into page-locked host memory
 int stx_host_chunks(stx_ctx *ctx, size_t bytes, size_t units);
 int stx_host_fence(stx_ctx *ctx);
 bool stx_host_is_pinned(const void *p, size_t bytes);
