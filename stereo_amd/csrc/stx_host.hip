@@ -644,6 +644,13 @@ int stx_disparity_resident_host(stx_ctx *ctx, const uint8_t *d_img0, const uint8
     if (rc) return rc;
     uint8_t *pin_out = (uint8_t *)ctx->pin_ptr[1];
     if (out_stride == op && stx_host_is_pinned(o, oimg)) pin_out = o;  // page-locked caller rows: direct
+    if (oimg <= ((size_t)4 << 20) && stx_host_zero_copy_on()) {  // a small map: stored straight into pinned memory
+        rc = stx_launch_disparity(ctx, d_img0, d_img1, 1, w, h, p, 0, 0, h, win, max_disp, cost_mode, pin_out, op, 0,
+                                  out_bytes);
+        if (rc) return rc;
+        STX_HIP(hipEventRecord(ctx->ev_k[0], ctx->stream));
+        return stx_host_download_end(ctx, o, out_stride, pin_out, op, (size_t)h, ctx->ev_k[0]);
+    }
     const int nc = stx_host_chunks(ctx, oimg, (size_t)(h + 63) / 64);
     int lo[STX_HOST_MAX_CHUNKS], cnt[STX_HOST_MAX_CHUNKS];
     for (int c = 0; c < nc; ++c) {
