@@ -66,6 +66,7 @@ extern "C" {
 #define STX_MATCH_MFMA 2  /* fp32 MFMA prefilter + exact replay of the running-minimum records */
 #define STX_MATCH_MFMA_BF16 3 /* same with the dot products as 3 bf16 MFMA products (hi/lo split) */
 #define STX_MATCH_MFMA_BF16X1 4 /* same with one bf16 MFMA product and a wider (still rigorous) bound */
+#define STX_MATCH_SMALL 5 /* exact scan with 16 lanes per query (what AUTO picks for small problems) */
 
 /* disparity kernel selector (stx_set_disparity_algo) */
 #define STX_DISP_AUTO 0       /* register sliding-sum kernel (win <= 31, max_disp <= 4096), else the LDS column-sum kernel */

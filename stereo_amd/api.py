@@ -37,7 +37,7 @@ HYP_FLOATS = 36      # STX_HYP_FLOATS, include/stereo_hip.h
 MATCH_FAILED, MATCH_SCORE, MATCH_RATIO, MATCH_ACCEPTED = 0, 1, 2, 3
 COST_SAD, COST_SSD = 0, 1
 RECT_PRESERVE_DST, RECT_DST_IS_ZERO = 0, 1
-MATCH_AUTO, MATCH_EXACT, MATCH_MFMA, MATCH_MFMA_BF16, MATCH_MFMA_BF16X1 = 0, 1, 2, 3, 4
+MATCH_AUTO, MATCH_EXACT, MATCH_MFMA, MATCH_MFMA_BF16, MATCH_MFMA_BF16X1, MATCH_SMALL = 0, 1, 2, 3, 4, 5
 DISP_AUTO, DISP_BRUTEFORCE, DISP_COLSUM = 0, 1, 2
 NOALLOC_MAX_PIXELS = 1 << 23  # STX_NOALLOC_MAX_PIXELS, include/stereo_hip.h
 

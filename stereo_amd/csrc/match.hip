@@ -1197,6 +1197,34 @@ __device__ __forceinline__ float small_dist(const float *__restrict__ q, const f
     return sqrtf(norm);
 }
 
+// the same for rows j, j + RP_L, j + 2 RP_L, j + 3 RP_L at once (rows beyond n2 repeat row j; unused)
+__device__ __forceinline__ void small_dist4(const float *__restrict__ q, const float *__restrict__ desc2, int j, int n2,
+                                            float (&out)[4])
+{
+    const float4 *b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int jr = j + r * RP_L < n2 ? j + r * RP_L : j;
+        b[r] = reinterpret_cast<const float4 *>(desc2 + (size_t)jr * K);
+    }
+    float norm[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+    for (int k4 = 0; k4 < K / 4; ++k4) {  // reference order per row: k ascending, one accumulator
+        const float4 qv = reinterpret_cast<const float4 *>(q)[k4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float4 bv = b[r][k4];
+            float d;
+            d = qv.x - bv.x; norm[r] = norm[r] + d * d;
+            d = qv.y - bv.y; norm[r] = norm[r] + d * d;
+            d = qv.z - bv.z; norm[r] = norm[r] + d * d;
+            d = qv.w - bv.w; norm[r] = norm[r] + d * d;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = sqrtf(norm[r]);
+}
+
 template <bool STORE>
 __global__ __launch_bounds__(64) void match_small_kernel(
     const float *__restrict__ desc1, const float *__restrict__ score1, int n1,
@@ -1220,13 +1248,23 @@ __global__ __launch_bounds__(64) void match_small_kernel(
     int bj = 0x7FFFFFFF;
     bool nan0 = false;
     if (live) {
+        // four rows per lane at a time: each distance is a dependent chain of 128 additions, and four
+        // independent chains fill the latency of one
 #pragma unroll 1
-        for (int j = l; j < n2; j += RP_L) {
-            const float dt = small_dist(q, desc2 + (size_t)j * K);
-            if (STORE) dist[j] = dt;
-            if (j == 0) { nan0 = dt != dt; d0 = dt; }  // list2[0] is taken unconditionally (:1041)
-            const float dd = dt == dt ? dt : inf;     // a later NaN never satisfies dist < minDist
-            if (dd < bd || (dd == bd && j < bj)) { bd = dd; bj = j; }  // (+inf rows too: the first one stays)
+        for (int j = l; j < n2; j += 4 * RP_L) {
+            float dt4[4];
+            small_dist4(q, desc2, j, n2, dt4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jr = j + r * RP_L;
+                if (jr < n2) {
+                    const float dt = dt4[r];
+                    if (STORE) dist[jr] = dt;
+                    if (jr == 0) { nan0 = dt != dt; d0 = dt; }  // list2[0] is taken unconditionally (:1041)
+                    const float dd = dt == dt ? dt : inf;      // a later NaN never satisfies dist < minDist
+                    if (dd < bd || (dd == bd && jr < bj)) { bd = dd; bj = jr; }  // (+inf rows too: the first one stays)
+                }
+            }
         }
     }
 #pragma unroll
@@ -1316,14 +1354,20 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
 {
     if (n1 <= 0) return STX_OK;
     int algo = ctx->match_algo;
+    if (algo == STX_MATCH_SMALL && n2 > 0)
+        return launch_small(ctx, d_desc1, d_score1, n1, d_desc2, d_score2, n2, dist_limit, d_closest, d_second,
+                            d_min_dist, d_second_dist, d_status);
+    if (algo == STX_MATCH_SMALL) algo = STX_MATCH_EXACT;
     if (algo == STX_MATCH_AUTO) {
-        if ((double)n1 * (double)n2 >= 4.0e6 && n2 >= 1024)
-            algo = STX_MATCH_MFMA_BF16X1;
-        else if (n2 > 0)
+        // measured (tools/exp/match_crossover.py): the small kernel takes ~9 us + 0.1 us per row of list2
+        // while its workgroups fit the chip at once, the prefilter + replay ~60 us + the matrix work
+        if (n2 == 0)
+            algo = STX_MATCH_EXACT;
+        else if (n2 <= 640 && (double)n1 * (double)n2 <= 4.0e6)
             return launch_small(ctx, d_desc1, d_score1, n1, d_desc2, d_score2, n2, dist_limit, d_closest, d_second,
                                 d_min_dist, d_second_dist, d_status);
         else
-            algo = STX_MATCH_EXACT;
+            algo = STX_MATCH_MFMA_BF16X1;
     }
     if (algo == STX_MATCH_EXACT || n2 == 0)
         return launch_exact(ctx, d_desc1, d_score1, n1, d_desc2, d_score2, n2, dist_limit, nullptr,

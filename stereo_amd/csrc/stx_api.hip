@@ -96,7 +96,7 @@ extern "C" int stx_set_match_algo(stx_ctx *ctx, int algo)
 {
     if (!ctx) return STX_ERR_INVALID_ARG;
     if (algo != STX_MATCH_AUTO && algo != STX_MATCH_EXACT && algo != STX_MATCH_MFMA &&
-        algo != STX_MATCH_MFMA_BF16 && algo != STX_MATCH_MFMA_BF16X1)
+        algo != STX_MATCH_MFMA_BF16 && algo != STX_MATCH_MFMA_BF16X1 && algo != STX_MATCH_SMALL)
         return STX_ERR_INVALID_ARG;
     ctx->match_algo = algo;
     return STX_OK;

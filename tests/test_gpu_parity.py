@@ -609,7 +609,7 @@ def _match_equal(got, want):
             assert g.tobytes() == w.tobytes(), "%s differs at %s" % (n, np.nonzero(g != w)[0][:8])
 
 
-ALGOS = [api.MATCH_EXACT, api.MATCH_MFMA, api.MATCH_MFMA_BF16, api.MATCH_MFMA_BF16X1, api.MATCH_AUTO]
+ALGOS = [api.MATCH_EXACT, api.MATCH_MFMA, api.MATCH_MFMA_BF16, api.MATCH_MFMA_BF16X1, api.MATCH_AUTO, api.MATCH_SMALL]
 
 
 @pytest.mark.parametrize("algo", ALGOS)
@@ -625,9 +625,10 @@ def test_match_matches_oracle(ctx, oracle, algo, n1, n2):
 
 @pytest.mark.parametrize("n1,n2", [(171, 210), (5, 17), (300, 9000), (5000, 700), (3, 8193)])
 def test_match_small_problem_kernel(ctx, oracle, n1, n2):
-    """What AUTO picks below the MFMA threshold (match_small_kernel: 16 lanes share a query): both
-    forms -- distances kept in LDS (n2 <= 8192) and recomputed -- against the oracle and against
-    the one-lane-per-query exact scan, with infinities, NaNs and all-equal rows in list2."""
+    """match_small_kernel (16 lanes share a query, four rows per lane at a time; what AUTO picks up to
+    640 rows of list2): both forms -- distances kept in LDS (n2 <= 8192) and recomputed -- against
+    the oracle, with AUTO's choice and the one-lane-per-query exact scan beside it; infinities, NaNs
+    and equal rows in list2."""
     d1, s1, d2, s2 = synth.descriptor_sets(n1 + 7 * n2, n1, n2)
     if n2 > 16:
         d2[0, 1] = np.inf           # +inf distance at j = 0: the first finite row becomes closest, second = 0
@@ -636,11 +637,12 @@ def test_match_small_problem_kernel(ctx, oracle, n1, n2):
         d1[0] = np.inf              # every distance of query 0 is inf or NaN
     want = oracle.match(d1, s1, d2, s2, 1000.0)
     _match_equal(ctx.match(d1, s1, d2, s2, 1000.0), want)
-    ctx.set_match_algo(api.MATCH_EXACT)
-    try:
-        _match_equal(ctx.match(d1, s1, d2, s2, 1000.0), want)
-    finally:
-        ctx.set_match_algo(api.MATCH_AUTO)
+    for algo in (api.MATCH_SMALL, api.MATCH_EXACT):
+        ctx.set_match_algo(algo)
+        try:
+            _match_equal(ctx.match(d1, s1, d2, s2, 1000.0), want)
+        finally:
+            ctx.set_match_algo(api.MATCH_AUTO)
 
 
 @pytest.mark.parametrize("algo", ALGOS)
