@@ -217,8 +217,13 @@ __global__ __launch_bounds__(256) void match_prep_frag_kernel(const float *__res
 }
 
 // squared norms (any summation order: covered by the error bound); padding rows get 0
+// seeds (x1 prefilter only, else nullptr): -|b_j|^2 / 2 per row (padding rows 0, unbounded rows +inf =
+// "-h" with h = -inf), written behind the fragments of the row's tile (tile_rows rows per tile of
+// tile_u4 uint4, the seeds seed_u4 uint4 into it)
 __global__ __launch_bounds__(256) void match_norm_kernel(const float *__restrict__ desc, int n, int npad,
-                                                         float *__restrict__ norm2, unsigned *__restrict__ max_bits)
+                                                         float *__restrict__ norm2, unsigned *__restrict__ max_bits,
+                                                         uint4 *__restrict__ seeds, int tile_rows, int tile_u4,
+                                                         int seed_u4)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
     float s = 0.f;
@@ -250,7 +255,12 @@ __global__ __launch_bounds__(256) void match_norm_kernel(const float *__restrict
     }
     // keep sums of two norms finite; anything larger (or inf/NaN) becomes NaN, which the
     // prefilter treats as "cannot be bounded": the row / query is always a candidate
-    norm2[r] = s <= 1e37f ? s : __builtin_nanf("");
+    const float nv = s <= 1e37f ? s : __builtin_nanf("");
+    norm2[r] = nv;
+    if (seeds) {
+        float *sd = reinterpret_cast<float *>(seeds + (size_t)(r / tile_rows) * tile_u4 + seed_u4);
+        sd[r % tile_rows] = nv == nv ? -0.5f * nv : __builtin_inff();
+    }
 }
 
 __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_kernel(
@@ -622,18 +632,6 @@ constexpr int MF_TILE_U4 = MF_TJ1 * 512 + 64;  // uint4 units per staged tile: f
 constexpr int X1_WAVES = 8;                    // waves per workgroup: one workgroup per CU, 2 waves per SIMD
 constexpr int X1_QB = X1_WAVES * MF_QW;        // queries per workgroup
 
-// -|b_j|^2 / 2 per row of list2 (padding rows 0, unbounded rows +inf = "-h" with h = -inf),
-// written behind the fragments of the row's tile
-__global__ __launch_bounds__(256) void match_neg_half_norm_kernel(const float *__restrict__ bnorm, int npad,
-                                                                   uint4 *__restrict__ frag16)
-{
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= npad) return;
-    const float s = bnorm[r];
-    float *seeds = reinterpret_cast<float *>(frag16 + (size_t)(r / MF_TILE_ROWS1) * MF_TILE_U4 + MF_TJ1 * 512);
-    seeds[r % MF_TILE_ROWS1] = s == s ? -0.5f * s : __builtin_inff();
-}
-
 __global__ __launch_bounds__(256) void match_prep_frag_bf16x1_kernel(const float *__restrict__ desc2, int n2,
                                                                      int n2pad, const float *__restrict__ bnorm,
                                                                      uint4 *__restrict__ frag16)
@@ -662,11 +660,12 @@ __global__ __launch_bounds__(256) void match_prep_frag_bf16x1_kernel(const float
 // Rows with a non-finite norm are always candidates and never part of the bound; a query that
 // yields nothing finite keeps -inf (= cold).  The candidates go to the query's last sub-list.
 constexpr int MF_WARM_ROWS = 32;
-__global__ __launch_bounds__(256) void match_warm_kernel(const float *__restrict__ desc1, const float *__restrict__ qnorm,
+__global__ __launch_bounds__(256) void match_warm_kernel(const float *__restrict__ desc1, float *__restrict__ qnorm,
                                                          int n1, const float *__restrict__ desc2, int n2,
                                                          const float *__restrict__ bnorm, const float *__restrict__ bmax,
                                                          float *__restrict__ yw, int nsub, int subcap,
-                                                         int *__restrict__ cand_count, int *__restrict__ cand)
+                                                         int *__restrict__ cand_count, int *__restrict__ cand,
+                                                         int *__restrict__ overflow_count)
 {
     __shared__ float rows[MF_WARM_ROWS][K];
     __shared__ float hn[MF_WARM_ROWS];
@@ -683,8 +682,18 @@ __global__ __launch_bounds__(256) void match_warm_kernel(const float *__restrict
         const float4 v = src[k];
         a[4 * k] = v.x; a[4 * k + 1] = v.y; a[4 * k + 2] = v.z; a[4 * k + 3] = v.w;
     }
+    // This kernel is the first to touch the query, so it also does the per-query set-up that used to be
+    // launches of their own: the squared norm (as match_norm_kernel sums it) for itself and the x1
+    // kernel, and the zeroing of the query's sub-list counts (the x1 kernel stores only the ones it uses).
+    float qn = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) qn = fmaf(a[k], a[k], qn);
+    qn = qn <= 1e37f ? qn : __builtin_nanf("");
+    qnorm[q] = qn;
+    for (int s = 0; s + 1 < nsub; ++s) cand_count[(size_t)q * nsub + s] = 0;
+    if (q == 0) *overflow_count = 0;
     // on y = -(d~ - |a|^2) / 2 the test d~' + e < d~ - e reads y < y' - e
-    const float e = MF_C * (qnorm[q] + *bmax) + MF_TINY;
+    const float e = MF_C * (qn + *bmax) + MF_TINY;
     int *list = cand + ((size_t)q * nsub + (nsub - 1)) * subcap;
     int cnt = 0;
     float best = -__builtin_inff();
@@ -1432,16 +1441,16 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     int *ovf_list = ovf_count + 4;
     int *cand = ovf_list + n1a;
     hipStream_t st = ctx->stream;
-    // (the x1 kernel stores the counts of the sub-lists it uses; the others must read 0)
-    STX_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (ncnt + 4), st));
+    // (the x1 kernel stores the counts of the sub-lists it uses; the others must read 0: its warm
+    // kernel zeroes them, per query, and the overflow count)
+    if (!x1) STX_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (ncnt + 4), st));
     const bool bf16 = algo == STX_MATCH_MFMA_BF16;
     unsigned *bmax = reinterpret_cast<unsigned *>(bnorm + n2pad);
     if (x1) STX_HIP(hipMemsetAsync(bmax, 0, sizeof(unsigned), st));
     hipLaunchKernelGGL(match_norm_kernel, dim3((n2pad + 255) / 256), dim3(256), 0, st, d_desc2, n2, n2pad, bnorm,
-                       x1 ? bmax : (unsigned *)nullptr);
+                       x1 ? bmax : (unsigned *)nullptr, x1 ? reinterpret_cast<uint4 *>(frag) : (uint4 *)nullptr,
+                       MF_TILE_ROWS1, MF_TILE_U4, MF_TJ1 * 512);
     if (x1) {
-        hipLaunchKernelGGL(match_neg_half_norm_kernel, dim3((n2pad + 255) / 256), dim3(256), 0, st, bnorm, n2pad,
-                           reinterpret_cast<uint4 *>(frag));
         hipLaunchKernelGGL(match_prep_frag_bf16x1_kernel, dim3((unsigned)(((size_t)n2pad / MF_JB * 512 + 255) / 256)),
                            dim3(256), 0, st, d_desc2, n2, n2pad, bnorm, reinterpret_cast<uint4 *>(frag));
     } else if (bf16)
@@ -1450,11 +1459,12 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     else
         hipLaunchKernelGGL(match_prep_frag_kernel, dim3((unsigned)(((size_t)n2pad * K / 4 + 255) / 256)), dim3(256),
                            0, st, d_desc2, n2, n2pad, frag);
-    hipLaunchKernelGGL(match_norm_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_desc1, n1, n1, qnorm,
-                       (unsigned *)nullptr);
+    if (!x1)
+        hipLaunchKernelGGL(match_norm_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_desc1, n1, n1, qnorm,
+                           (unsigned *)nullptr, (uint4 *)nullptr, 1, 0, 0);
     if (x1) {
         hipLaunchKernelGGL(match_warm_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_desc1, qnorm, n1, d_desc2, n2,
-                           bnorm, reinterpret_cast<const float *>(bmax), ywarm, nsub, subcap, cnt, cand);
+                           bnorm, reinterpret_cast<const float *>(bmax), ywarm, nsub, subcap, cnt, cand, ovf_count);
         hipLaunchKernelGGL(match_mfma_bf16x1_kernel, dim3(x1_wgs), dim3(X1_WAVES * 64), 0, st, d_desc1, qnorm,
                            n1, reinterpret_cast<const uint4 *>(frag), reinterpret_cast<const float *>(bmax), n2,
                            tiles_total, per, flat_total, nsub, subcap, cnt, cand, ywarm);
