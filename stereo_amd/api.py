@@ -513,14 +513,19 @@ class MultiContext:
             check(self._lib.stx_set_match_algo(self._lib.stx_multi_context(self._h, k), int(algo)),
                   "stx_set_match_algo")
 
-    def disparity_batch(self, img0, img1, win=1, max_disp=0, cost_mode=COST_SAD):
+    def disparity_batch(self, img0, img1, win=1, max_disp=0, cost_mode=COST_SAD, out=None):
         """img0/img1: [n,H,W] uint8 arrays (a batch of pairs, dealt to the devices in contiguous
-        shares).  Returns the [n,H,W] uint8 maps."""
+        shares).  Returns the [n,H,W] uint8 maps (written into `out` when given: a C-contiguous
+        [n,H,W] uint8 array, e.g. page-locked memory)."""
         a, b = np.ascontiguousarray(img0, np.uint8), np.ascontiguousarray(img1, np.uint8)
         if a.ndim != 3 or a.shape != b.shape:
             raise ValueError("img0 and img1 must be [n,H,W] arrays of one shape")
         n, h, w = a.shape
-        out = np.zeros((n, h, w), np.uint8)
+        if out is None:
+            out = np.zeros((n, h, w), np.uint8)
+        elif not (isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.shape == a.shape
+                  and out.flags.c_contiguous and out.flags.writeable):
+            raise ValueError("out must be a writable C-contiguous [n,H,W] uint8 array")
         check(self._lib.stx_disparity_batch_u8(self._h, _ptr(a), _ptr(b), n, w, h, max(w, 1), max(w, 1) * h,
                                                int(win), int(max_disp), int(cost_mode), _ptr(out), max(w, 1),
                                                max(w, 1) * h), "stx_disparity_batch_u8")

@@ -481,6 +481,12 @@ int stx_disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, i
     uint8_t *dout = (uint8_t *)stx_workspace(ctx, STX_SLOT_OUT, oimg * group, &err);
     if (!dout) return err;
     uint8_t *pin_in = (uint8_t *)ctx->pin_ptr[0], *pin_out = (uint8_t *)ctx->pin_ptr[1];
+    // page-locked, dense caller arrays (checked over the whole batch) are read / written by the DMA
+    // engines directly: the staging copies are what bounds a pageable batch
+    const size_t span = (size_t)(n_pairs - 1) * pair_stride + img;
+    const bool in_direct = stride == p && stx_host_is_pinned(img0 + (size_t)b0 * stride, span) &&
+                           stx_host_is_pinned(img1 + (size_t)b0 * stride, span);
+    const bool out_direct = out_stride == op && out_pair_stride == oimg && stx_host_is_pinned(o, (size_t)n_pairs * oimg);
     for (int g0 = 0; g0 < n_pairs; g0 += group) {
         const int g = n_pairs - g0 < group ? n_pairs - g0 : group;
         const int nc = stx_host_chunks(ctx, per_pair * g, (size_t)g);
@@ -490,25 +496,42 @@ int stx_disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, i
         for (int c = 0; c < nc; ++c) {
             lo[c] = (int)((long long)g * c / nc);
             cnt[c] = (int)((long long)g * (c + 1) / nc) - lo[c];
-            for (int k = lo[c]; k < lo[c] + cnt[c]; ++k) {
-                const size_t off = (size_t)(g0 + k) * pair_stride + (size_t)b0 * stride;
-                rc = stx_host_upload(ctx, d0 + k * img, pin_in + (size_t)k * img, img0 + off, stride, p, bh, nullptr);
-                if (rc) return rc;
-                rc = stx_host_upload(ctx, d1 + k * img, pin_in + ((size_t)group + k) * img, img1 + off, stride, p, bh,
-                                     k == lo[c] + cnt[c] - 1 ? ctx->ev_in[c] : nullptr);
-                if (rc) return rc;
+            // page-locked and dense: one DMA per image array and chunk, not per pair (a copy costs ~10 us
+            // before its first byte)
+            const size_t first = (size_t)(g0 + lo[c]) * pair_stride + (size_t)b0 * stride;
+            const size_t cbytes = (size_t)cnt[c] * img;
+            if (in_direct && (pair_stride == img || cnt[c] == 1)) {
+                STX_HIP(hipMemcpyAsync(d0 + lo[c] * img, img0 + first, cbytes, hipMemcpyHostToDevice, ctx->s_in));
+                STX_HIP(hipMemcpyAsync(d1 + lo[c] * img, img1 + first, cbytes, hipMemcpyHostToDevice, ctx->s_in));
+            } else if (in_direct) {
+                for (int k = lo[c]; k < lo[c] + cnt[c]; ++k) {
+                    const size_t off = (size_t)(g0 + k) * pair_stride + (size_t)b0 * stride;
+                    STX_HIP(hipMemcpyAsync(d0 + k * img, img0 + off, img, hipMemcpyHostToDevice, ctx->s_in));
+                    STX_HIP(hipMemcpyAsync(d1 + k * img, img1 + off, img, hipMemcpyHostToDevice, ctx->s_in));
+                }
+            } else {  // pageable: pair by pair, so that the staging copy of one image runs behind the DMA of the last
+                for (int k = lo[c]; k < lo[c] + cnt[c]; ++k) {
+                    const size_t off = (size_t)(g0 + k) * pair_stride + (size_t)b0 * stride;
+                    rc = stx_host_upload(ctx, d0 + k * img, pin_in + (size_t)k * img, img0 + off, stride, p, bh, nullptr);
+                    if (rc) return rc;
+                    rc = stx_host_upload(ctx, d1 + k * img, pin_in + ((size_t)group + k) * img, img1 + off, stride, p, bh,
+                                         nullptr);
+                    if (rc) return rc;
+                }
             }
+            STX_HIP(hipEventRecord(ctx->ev_in[c], ctx->s_in));
             STX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_in[c], 0));
             rc = stx_launch_disparity(ctx, d0 + lo[c] * img, d1 + lo[c] * img, cnt[c], w, bh, p, img, row0 - b0, rows,
                                       win, max_disp, cost_mode, dout + lo[c] * oimg, op, oimg, out_bytes);
             if (rc) return rc;
             STX_HIP(hipEventRecord(ctx->ev_k[c], ctx->stream));
-            rc = stx_host_download_begin(ctx, pin_out + lo[c] * oimg, dout + lo[c] * oimg, cnt[c] * oimg, ctx->ev_k[c],
-                                         ctx->ev_out[c]);
+            rc = stx_host_download_begin(ctx, out_direct ? o + (size_t)(g0 + lo[c]) * oimg : pin_out + lo[c] * oimg,
+                                         dout + lo[c] * oimg, cnt[c] * oimg, ctx->ev_k[c], ctx->ev_out[c]);
             if (rc) return rc;
         }
         for (int c = 0; c < nc; ++c) {
             STX_HIP(hipEventSynchronize(ctx->ev_out[c]));
+            if (out_direct) continue;
             for (int k = lo[c]; k < lo[c] + cnt[c]; ++k)
                 pool_copy2d(ctx, o + (size_t)(g0 + k) * out_pair_stride, out_stride, pin_out + (size_t)k * oimg, op, op,
                             (size_t)rows);

@@ -409,6 +409,19 @@ def test_page_locked_caller_buffers_skip_the_staging(ctx, oracle):
             pd[...] = 7
             ctx.rectify(ps, pd, Hinv, api.RECT_DST_IS_ZERO)
             assert (pd == wantr).all()
+            # a batch through the multi-device handle: pinned inputs and output, then mixed
+            from stereo_amd import MultiContext
+            batch_l, batch_r = np.stack([l[:200], l[100:300], l[200:400]]), np.stack([r[:200], r[100:300], r[200:400]])
+            tbl, pbl = pinned(batch_l)
+            tbr, pbr = pinned(batch_r)
+            tbo, pbo = pinned(np.zeros_like(batch_l))
+            want_b = np.stack([oracle.disparity_ext(batch_l[k], batch_r[k], 9, 64, 0, sliding=True) for k in range(3)])
+            mc = MultiContext([0])
+            try:
+                assert (mc.disparity_batch(pbl, pbr, win=9, max_disp=64, out=pbo) == want_b).all()
+                assert (mc.disparity_batch(pbl, batch_r, win=9, max_disp=64) == want_b).all()
+            finally:
+                mc.close()
             ctx.rectify_keep(0, ps, pd, Hinv)
             ctx.rectify_keep(1, ps, pd, Hinv)
             assert (ctx.disparity_resident(0, 1, (h, w), out=po) == oracle.disparity_ref(wantr, wantr)).all()

@@ -65,6 +65,16 @@ row = [best(lambda: ctx.disparity(pl, pr, win=9, max_disp=D, out=pdout)), best(l
 print("%-12s " % "pinned t0 c0" + " ".join("%8.3f / %8.3f ms" % v for v in row), flush=True)
 b, m = best(lambda: mc.disparity_batch(ba, bb, win=9, max_disp=192), 5)
 print("stx_disparity_batch_u8, 32 x 1080p pairs, D=192, 1 device: best %.2f ms median %.2f ms = %.0f pairs/s" % (b, m, 32 / m * 1e3))
+def pinned3(a):
+    t = torch.empty(a.shape, dtype=torch.uint8, pin_memory=True)
+    v = t.numpy()
+    v[...] = a
+    return t, v
+
+
+keep3 = [pinned3(x) for x in (ba, bb, np.zeros_like(ba))]
+b, m = best(lambda: mc.disparity_batch(keep3[0][1], keep3[1][1], win=9, max_disp=192, out=keep3[2][1]), 5)
+print("the same batch from and into page-locked arrays:               best %.2f ms median %.2f ms = %.0f pairs/s" % (b, m, 32 / m * 1e3))
 print("(best / median of the calls; outputs written into reused arrays except for the fused call and matching)")
 # matching at config 5's size through host pointers: separate arrays vs the reference's 540-byte records
 n = 200000
