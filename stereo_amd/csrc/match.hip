@@ -1421,9 +1421,14 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     // Workgroups b and b + 8 share an XCD and its L2.  With every range starting at a multiple
     // of tiles_total / 32, the 64 workgroups of an XCD stream list2 at no more than 4 distinct
     // positions, in step, so all but the first reader of a tile hit in L2.
+    // (Not when the rounding would leave CUs without work: with few query blocks -- list1 sharded
+    // over GPUs -- a range is a fraction of list2 and rounding it up to the next 1/32 can idle an
+    // eighth of the chip, more than the alignment is worth.)
     if (tiles_total % 32 == 0 && tiles_total >= 256) {
         const long long u = tiles_total / 32;
-        per = (per + u - 1) / u * u;
+        const long long per_aligned = (per + u - 1) / u * u;
+        const long long wgs_aligned = (flat_total + per_aligned - 1) / per_aligned;
+        if (wgs_aligned * 100 >= (long long)slots * 96) per = per_aligned;
     }
     const int x1_wgs = (int)((flat_total + per - 1) / per);
     const int max_pieces = (int)((tiles_total + per - 1) / per) + 1;
