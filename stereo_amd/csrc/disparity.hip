@@ -707,8 +707,6 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
                     cost[0] = edge - n0;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        constexpr int unused = 0;
-                        (void)unused;
                         const int take = c + 1 + R, dropd = R - c;  // columns to the right / left of column 0
                         unsigned tk, dr;
                         switch (take / 4) {
