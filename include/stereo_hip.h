@@ -221,12 +221,11 @@ int stx_disparity_dev(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_img1
 /* The same scan for callers that cannot allocate: code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.  Arguments and
  * results are exactly stx_disparity_dev's.  The one scratch buffer the scan needs -- the
- * per-pixel keys carried between passes when more than 256 disparities are searched (128 with a
- * 31x31 window) -- is a
+ * per-pixel keys carried between passes when more than 256 disparities are searched -- is a
  * static device array inside the library, so this call never calls hipMalloc / hipFree (nor any
  * allocating library routine).  Limit: a scan of more than 256 disparities may cover at most
  * STX_NOALLOC_MAX_PIXELS pixels (n_pairs * w * h; one 3840x2160 pair fits), else
- * STX_ERR_TOO_LARGE; scans of up to 256 (31x31: 128) disparities need no scratch and have no such limit.
+ * STX_ERR_TOO_LARGE; scans of up to 256 disparities need no scratch and have no such limit.
  * Every call on one GPU shares that GPU's array (32 MiB, held until the process ends): calls
  * that overlap on one GPU -- from any context or stream -- race.  Asynchronous. */
 #define STX_NOALLOC_MAX_PIXELS (1 << 23)

@@ -248,6 +248,10 @@ __global__ __launch_bounds__(EXT_THREADS) void disp_ext_bruteforce_kernel(
 // up to 13x13, 20 for 15x15 (32 rows would not fit the LDS next to 16 waves' img1 columns)
 constexpr int band_ring(int win) { return win + 2 <= 16 ? 16 : win + 2 <= 20 ? 20 : win + 2; }
 template <int RING> __device__ __forceinline__ int band_slot(int yy) { return (yy + 4 * RING) % RING; }
+// The mask rows are read only for the centre row of the window, win / 2 rows behind the entering
+// one: the wide windows (17x17 and up), whose image rows need up to 33 ring rows, keep just
+// win / 2 + 2 mask rows, which is what lets 31x31 search 256 disparities in one pass.
+constexpr int band_mask_ring(int win) { return win > 15 ? win / 2 + 2 : band_ring(win); }
 constexpr int BAND_ND = 16;          // disparities per wave
 constexpr int BAND_COLS = 256;       // columns per tile (64 lanes x 4)
 constexpr unsigned BAND_SH = 12;     // key = cost << 12 | (4095 - d)
@@ -446,7 +450,8 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     constexpr int TILE_OUT = WIDE ? 16 * OL : BAND_COLS - 8 * HL;
     constexpr int RING = band_ring(WIN);
     static_assert(!WIDE || ((255ull * WIN * WIN) << BAND_SH) + 4095ull < BAND_INIT, "wide SAD key width");
-    static_assert(WIN + 2 <= RING && RING >= 8, "ring too small");
+    constexpr int RING_M = band_mask_ring(WIN);
+    static_assert(WIN + 2 <= RING && RING >= 8 && R + 2 <= RING_M, "ring too small");
 
     extern __shared__ u32x4 band_lds4[];
     const int nw = blockDim.x >> 6;
@@ -454,11 +459,11 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
     const int rw = 4 * rw4;                              // img1 columns per ring row
     u32x4 *Lrow4 = band_lds4;                            // [RING][64]
     u32x4 *Rrow4 = Lrow4 + RING * (BAND_COLS / 4);  // [RING][rw4]
-    u32x4 *Mrow4 = Rrow4 + RING * rw4;              // [RING][rw4]
+    u32x4 *Mrow4 = Rrow4 + RING * rw4;              // [RING_M][rw4]
     unsigned *Lrow = reinterpret_cast<unsigned *>(Lrow4);
     unsigned *Rrow = reinterpret_cast<unsigned *>(Rrow4);
     unsigned *Mrow = reinterpret_cast<unsigned *>(Mrow4);
-    unsigned *best = reinterpret_cast<unsigned *>(Mrow4 + RING * rw4);  // [2][256]
+    unsigned *best = reinterpret_cast<unsigned *>(Mrow4 + RING_M * rw4);  // [2][256]
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
                 // PK: the low half of a mask word is the img1 COLUMN x1 of the candidate -- the key's
                 // tie-break code (lower x1 wins, the reference's first-wins order) travels with the
                 // mask, so a key is one shift-or / and-or of (cost, mask word)
-                Mrow[slot * rw + i] = PK ? ((fill_r[k] ? 0u : PK_MASKED) | ((unsigned)(rbase + i) & 0xFFFFu))
+                Mrow[band_slot<RING_M>(yy) * rw + i] = PK ? ((fill_r[k] ? 0u : PK_MASKED) | ((unsigned)(rbase + i) & 0xFFFFu))
                                          : fill_r[k] ? 0u : (SSDW ? SSDW_MASKED : BAND_MASKED);
             }
         }
@@ -668,9 +673,8 @@ __global__ __launch_bounds__(BAND_MAX_WAVES * 64) void disp_band_kernel(BandArgs
         // ---- output row y = ys - R: window sums, keys, winner-take-all --------
         const int y = ys - R;
         if (active && y >= yb) {
-            const int slot = band_slot<RING>(y);
             unsigned mv[20];
-            lds_read_5(Mrow4 + slot * rw4 + roff4, mv);
+            lds_read_5(Mrow4 + band_slot<RING_M>(y) * rw4 + roff4, mv);
             unsigned m[4] = {~0u, ~0u, ~0u, ~0u};
             unsigned pend[4];
 #pragma unroll
@@ -1103,12 +1107,13 @@ int launch_band(stx_ctx *ctx, BandArgs a, int n_pairs, void *keys, size_t keys_b
     constexpr int HL = (R + 3) / 4;
     constexpr int TILE_OUT = R > 7 ? 16 * (16 - 2 * HL) : BAND_COLS - 8 * HL;
     const int xt = (a.w + TILE_OUT - 1) / TILE_OUT;
-    // disparities per pass: 16 waves' worth, or 8 where 16 waves' img1 columns would not fit the
-    // LDS next to the ring (31x31: 33 ring rows)
+    // disparities per pass: 16 waves' worth (or 8, should 16 waves' img1 columns not fit the LDS
+    // next to the ring)
     constexpr size_t LDS_MAX = 160 * 1024;
-    constexpr int RING_ROWS = band_ring(2 * R + 1);
+    constexpr int RING_ROWS = band_ring(2 * R + 1), RING_M = band_mask_ring(2 * R + 1);
     constexpr int BEST_WORDS = (SSD && R > 7 ? 4 : 2) * BAND_COLS;  // wide SSD: 64-bit keys
-    constexpr int NW_MAX = sizeof(unsigned) * ((size_t)RING_ROWS * (BAND_COLS + 2 * (BAND_COLS + BAND_ND * BAND_MAX_WAVES)) + BEST_WORDS) <= LDS_MAX
+    constexpr int RW_MAX = BAND_COLS + BAND_ND * BAND_MAX_WAVES;
+    constexpr int NW_MAX = sizeof(unsigned) * ((size_t)RING_ROWS * (BAND_COLS + RW_MAX) + (size_t)RING_M * RW_MAX + BEST_WORDS) <= LDS_MAX
                                ? BAND_MAX_WAVES : BAND_MAX_WAVES / 2;
     const int passD = BAND_ND * NW_MAX;
     const int npass = (a.D + passD - 1) / passD;
@@ -1149,7 +1154,7 @@ int launch_band(stx_ctx *ctx, BandArgs a, int n_pairs, void *keys, size_t keys_b
         a.first_pass = p == 0;
         a.last_pass = p == npass - 1;
         const int rw = BAND_COLS + BAND_ND * nw;
-        const size_t lds = sizeof(unsigned) * ((size_t)band_ring(2 * R + 1) * (BAND_COLS + 2 * rw) + BEST_WORDS);
+        const size_t lds = sizeof(unsigned) * ((size_t)RING_ROWS * (BAND_COLS + rw) + (size_t)RING_M * rw + BEST_WORDS);
         const int rc = stx_set_lds_attr(ctx, reinterpret_cast<const void *>(disp_band_kernel<R, SSD>), (int)lds);
         if (rc != STX_OK) return rc;
         hipLaunchKernelGGL((disp_band_kernel<R, SSD>), dim3(xt, bands, n_pairs), dim3(64 * nw), lds,

@@ -150,7 +150,7 @@ def test_disparity_wide_windows_every_radius(ctx, oracle, win, h, w, D, cm):
     """17x17 .. 31x31 run the register kernel with the wave cut into four 16-lane rows (row_shr /
     row_shl DPP): every radius has its own fetch distances, so every radius is checked, SAD and SSD
     (64-bit keys across the waves) -- several 128/160/192-column tiles, row bands, partial
-    disparity blocks, two to five passes (31x31 searches 128 disparities per pass), u16 output."""
+    disparity blocks, two and three passes, u16 output."""
     a, b = _rand_pair(win * 7 + h + w + D + cm, h, w, zero=0.03)
     dt = np.uint16 if D > 256 else np.uint8
     want = oracle.disparity_ext(a, b, win, D, cm, dt, sliding=True)
