@@ -44,7 +44,7 @@ run("disp_band_9x9_ssd_d256_2880x1988", "disp_band_kernel<4, true>", 1,
     lambda: ctx.disparity_dev(d_l, d_r, d_o, win=WIN, max_disp=D, cost_mode=api.COST_SSD))
 run("disp_band_21x21_sad_d256_2880x1988", "disp_band_kernel<10, false>", 1,
     lambda: ctx.disparity_dev(d_l, d_r, d_o, win=21, max_disp=D))
-run("disp_band_31x31_ssd_d256_2880x1988", "disp_band_kernel<15, true>", 2,
+run("disp_band_31x31_ssd_d256_2880x1988", "disp_band_kernel<15, true>", 1,
     lambda: ctx.disparity_dev(d_l, d_r, d_o, win=31, max_disp=D, cost_mode=api.COST_SSD))
 w3, h3, D3 = 3840, 2160, 512
 l3, r3 = synth.rectified_pair(303, h3, w3, D3)
