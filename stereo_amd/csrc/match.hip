@@ -712,6 +712,16 @@ __global__ __launch_bounds__(256) void match_warm_kernel(const float *__restrict
     yw[q] = best;
 }
 
+// The folds below are inline asm, which the compiler's hazard recognizer does not cover: an ordinary
+// VALU read of an MFMA result gets the wait states the ISA requires (the hardware does not interlock),
+// an asm operand does not.  Where a fold follows the MFMAs that write its operands directly, this
+// pads by hand (24 wait states, more than any 8-pass MFMA needs); taking both accumulators in and out
+// orders it behind their last MFMAs and ahead of every later read.
+__device__ __forceinline__ void mfma_results_settle(f32x16 &a, f32x16 &b)
+{
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a), "+v"(b));
+}
+
 struct BoundX1 {
     float Y;        // running max of y over the rows seen so far
     float T;        // Y - e: rows with y < T cannot be records
@@ -1029,6 +1039,7 @@ __global__ __launch_bounds__(X1_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
 #undef X1_BLOCK
         {   // drain: the last block (in y0, y1)
             const int j0 = (t_end - 1) * MF_TILE_ROWS1 + 3 * MF_JB;
+            mfma_results_settle(y0, y1);
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 asm("v_max3_f32 %0, %0, %1, %2" : "+v"(b0.M) : "v"(y0[r]), "v"(y0[r + 1]));
