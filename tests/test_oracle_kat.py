@@ -65,7 +65,8 @@ def test_disparity_ext_collapses_to_reference(oracle):
     assert (oracle.disparity_ext(img0, img1, 1, 0) == oracle.disparity_ref(img0, img1)).all()
 
 
-@pytest.mark.parametrize("win,D,cm", [(1, 5, 0), (3, 9, 0), (5, 16, 1), (9, 33, 0), (7, 64, 1)])
+@pytest.mark.parametrize("win,D,cm", [(1, 5, 0), (3, 9, 0), (5, 16, 1), (9, 33, 0), (7, 64, 1), (13, 20, 1), (15, 40, 0),
+                                      (17, 40, 0), (21, 30, 1), (27, 57, 0), (31, 64, 0), (31, 20, 1)])
 def test_disparity_ext_sliding_equals_bruteforce(oracle, win, D, cm):
     rng = np.random.RandomState(win * 100 + D)
     img0 = rng.randint(0, 256, (23, 57)).astype(np.uint8)
