@@ -96,7 +96,7 @@ def test_reference_mode_scan_two_restatements_agree(oracle, h, w, seed):
 
 
 @pytest.mark.parametrize("win,D,ssd", [(1, 9, 0), (3, 16, 0), (5, 40, 1), (9, 24, 0), (13, 20, 1), (15, 33, 0),
-                                       (21, 12, 1), (9, 300, 0)])
+                                       (21, 12, 1), (9, 300, 0), (17, 30, 1), (31, 25, 0)])
 def test_windowed_scan_two_restatements_agree(oracle, win, D, ssd):
     rng = np.random.RandomState(win * 100 + D)
     h, w = (18, 70) if D < 100 else (6, 340)
