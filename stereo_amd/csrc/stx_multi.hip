@@ -9,6 +9,7 @@
 // caller's memory and writes its share of the result straight back to the caller's output, so
 // there is no device-to-device step to pay for (the one-process-per-GPU form with an RCCL
 // gather lives in stereo_amd/dist.py).
+#include <cstdlib>
 #include <new>
 #include <thread>
 
@@ -47,10 +48,15 @@ extern "C" int stx_multi_create(stx_multi **out, const int *device_ids, int n_de
     if (e != hipSuccess) return (int)e;
     if (n_devices == 0) n_devices = have < STX_MULTI_MAX_DEVICES ? have : STX_MULTI_MAX_DEVICES;
     if (n_devices == 0) return STX_ERR_NO_DEVICE;
+    // Test-only switch: STX_MULTI_ALLOW_REPEAT=1 lets a device id appear more than once, so the
+    // threaded n >= 2 path (shares, halo uploads, one staging pool per context) runs on a one-GPU
+    // box.  Two contexts on one device are independent (own stream, own workspace slots).
+    const char *rep = getenv("STX_MULTI_ALLOW_REPEAT");
+    const bool allow_repeat = rep && rep[0] == '1' && rep[1] == 0;
     for (int k = 0; k < n_devices; ++k) {
         const int d = device_ids ? device_ids[k] : k;
         if (d < 0 || d >= have) return STX_ERR_NO_DEVICE;
-        for (int j = 0; j < k; ++j)
+        for (int j = 0; j < k && !allow_repeat; ++j)
             if ((device_ids ? device_ids[j] : j) == d) return STX_ERR_INVALID_ARG;  // a device twice
     }
     stx_multi *m = new (std::nothrow) stx_multi();

@@ -33,34 +33,56 @@ def row_band(full_h, rank, world, halo):
     return row0, row1 - row0, b0, b1 - b0
 
 
+def _wire(t):
+    """The tensor as rows of bytes: what actually travels.
+
+    torch's NCCL (= RCCL) type map has no 16-bit integer (NCCLUtils.hpp getNcclDataType: uint8,
+    int8, int32, int64, half, float, double, bfloat16 ...), so a u16 disparity map (config 3)
+    cannot be posted as it is.  Nothing on this path is a reduction -- the element type means
+    nothing to the transport -- so every block goes out as uint8 and is viewed back on the root."""
+    t = t.contiguous()
+    rows = int(t.shape[0])
+    return t.view(torch.uint8).reshape(rows, -1) if t.numel() else t.new_empty((rows, 0), dtype=torch.uint8)
+
+
 def gather_rows(local, counts, dst=0, group=None):
     """Gather per-rank row blocks (dim 0, sizes `counts`) to rank `dst`.
 
     Point-to-point sends into the root (grouped isend/irecv): on an 8-GPU
-    xGMI node that is 7 concurrent links into the root.  Returns the
-    concatenated tensor on `dst`, None elsewhere."""
+    xGMI node that is 7 concurrent links into the root.  Only uint8 tensors are
+    handed to the backend (see _wire).  Returns the concatenated tensor on
+    `dst`, None elsewhere."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1:
         return local
+    if len(counts) != world or int(counts[rank]) != int(local.shape[0]):
+        raise ValueError("gather_rows: counts[%d] = %s does not describe this rank's %d rows"
+                         % (rank, counts[rank] if len(counts) == world else "?", int(local.shape[0])))
+    tail = tuple(local.shape[1:])
+    row_bytes = local.element_size()
+    for d in tail:
+        row_bytes *= int(d)
     if rank == dst:
-        parts = []
+        # one buffer for the whole result: every receive lands in its final place (no torch.cat copy)
+        total = sum(int(c) for c in counts)
+        out = torch.empty((total,) + tail, dtype=local.dtype, device=local.device)
+        wire = out.view(torch.uint8).reshape(total, row_bytes) if out.numel() else None
         ops = []
+        at = 0
         for r in range(world):
+            c = int(counts[r])
             if r == dst:
-                parts.append(local)
-                continue
-            buf = torch.empty((counts[r],) + tuple(local.shape[1:]), dtype=local.dtype,
-                              device=local.device)
-            parts.append(buf)
-            if counts[r] > 0:
-                ops.append(dist.P2POp(dist.irecv, buf, r, group))
+                out[at:at + c] = local
+            elif c > 0 and row_bytes > 0:
+                ops.append(dist.P2POp(dist.irecv, wire[at:at + c], r, group))
+            at += c
         # one group: on RCCL the receives are posted together and run on all links at once
         for q in (dist.batch_isend_irecv(ops) if ops else []):
             q.wait()
-        return torch.cat(parts, dim=0)
-    if local.shape[0] > 0:
-        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), dst, group)]):
+        return out
+    if local.shape[0] > 0 and row_bytes > 0:
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, _wire(local), dst, group)]):
             q.wait()
     return None
 

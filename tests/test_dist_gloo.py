@@ -135,3 +135,87 @@ def test_rectify_and_match_sharding_world2():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ------------------------------------------------ what reaches the backend's type map ----
+
+# torch/include/torch/csrc/distributed/c10d/NCCLUtils.hpp, getNcclDataType: the element types
+# torch's NCCL (= RCCL) backend accepts.  There is no 16-bit integer among them; gloo takes
+# anything, so only a check on the tensors handed to P2POp sees a u16 map on its way to RCCL.
+NCCL_DTYPES = {torch.uint8, torch.int8, torch.int32, torch.int64, torch.float16, torch.float32,
+               torch.float64, torch.bfloat16, torch.bool}
+
+
+def _worker_wire(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stereo_amd import dist as sdist
+        seen = []
+        real = dist.P2POp
+
+        def checked(op, tensor, peer, group=None, *a, **k):
+            seen.append(tensor.dtype)
+            assert tensor.dtype in NCCL_DTYPES, "a %s tensor would reach RCCL" % tensor.dtype
+            assert tensor.is_contiguous()
+            return real(op, tensor, peer, group, *a, **k)
+
+        dist.P2POp = checked
+        ok = True
+        # config 3's u16 map cut into row bands (3 columns wide, so a row is an odd number of u16s)
+        full = (torch.arange(7 * 3, dtype=torch.int32).reshape(7, 3) * 2500 % 65536).to(torch.uint16)
+        for dt in (torch.uint16, torch.int16, torch.uint8, torch.int32, torch.float32):
+            f = full.view(torch.int16).to(dt) if dt not in (torch.uint16,) else full
+            got = sdist.disparity_rowbands(
+                lambda i0, i1, b0, fh, row0, rows: f[row0:row0 + rows].clone(), f, f, 3)
+            if rank == 0:
+                ok = ok and got.dtype == dt and got.shape == f.shape and got.view(torch.uint8).tolist() == f.view(torch.uint8).tolist()
+            else:
+                ok = ok and got is None
+        # the five per-query arrays of matching and the two of RANSAC scoring, ragged shares (n = 5)
+        arrs = (torch.arange(5, dtype=torch.int32), -torch.arange(5, dtype=torch.int32),
+                torch.arange(5, dtype=torch.float32) / 3, torch.arange(5, dtype=torch.float32) / 7,
+                torch.arange(5, dtype=torch.uint8))
+        res = sdist.match_sharded(lambda lo, hi: tuple(a[lo:hi].clone() for a in arrs), 5)
+        if rank == 0:
+            ok = ok and all(g.dtype == a.dtype and g.tolist() == a.tolist() for g, a in zip(res, arrs))
+        res = sdist.ransac_sharded(lambda lo, hi: (arrs[0][lo:hi].clone(), arrs[2][lo:hi].clone()), 5)
+        if rank == 0:
+            ok = ok and res[0].tolist() == arrs[0].tolist() and res[1].tolist() == arrs[2].tolist()
+        # an empty share (1 row over 2 ranks) and a multi-dimensional block (pairs of config 4)
+        one = torch.full((1, 4), 9, dtype=torch.uint16)
+        got = sdist.rectify_rowbands(lambda row0, rows: one[row0:row0 + rows].clone(), 1)
+        if rank == 0:
+            ok = ok and got.tolist() == one.tolist()
+        maps = torch.arange(3 * 2 * 5, dtype=torch.uint8).reshape(3, 2, 5)
+        lo, hi = sdist.shard_range(3, rank, world)
+        got = sdist.gather_rows(maps[lo:hi].clone(), [2, 1], 0)
+        if rank == 0:
+            ok = ok and got.tolist() == maps.tolist()
+        # a count that does not describe the block is refused before anything is posted
+        try:
+            sdist.gather_rows(maps[lo:hi].clone(), [1, 2], 0)
+            ok = False
+        except ValueError:
+            pass
+        ok = ok and len(seen) > 0 and set(seen) == {torch.uint8}
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_only_bytes_reach_the_backend_world2():
+    """the u16 map of config 3 went to dist.P2POp as torch.int16, which RCCL's type
+    map rejects.  Every tensor handed to the backend must have a dtype of that map."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30300 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_worker_wire, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
