@@ -18,6 +18,17 @@ def main():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     from stereo_amd.dist import _wire
     band = (torch.arange(270 * 3840, device="cuda", dtype=torch.int32) % 65536).to(torch.uint16).reshape(270, 3840)
+    got = torch.empty_like(band)
+    # send first: RCCL pairs a receive from self with a send already queued in the group (the
+    # other order copies nothing on this version); between real ranks each side posts one kind only
+    ops = [dist.P2POp(dist.isend, _wire(band), 0), dist.P2POp(dist.irecv, _wire(got), 0)]
+    for q in dist.batch_isend_irecv(ops):
+        q.wait()
+    torch.cuda.synchronize()
+    same = bool(torch.equal(got.view(torch.uint8), band.view(torch.uint8)))
+    print("bytes round trip equal:", same)
+    # last: a refused batch leaves the group half-open on this torch version (a later batch on
+    # the same group then copies nothing), and the product never posts such a tensor
     refused = False
     try:
         t = band.view(torch.int16)
@@ -27,13 +38,6 @@ def main():
         refused = True
         print("int16 refused:", str(e).splitlines()[0])
     print("int16 refused by the backend:", refused)
-    got = torch.empty_like(band)
-    ops = [dist.P2POp(dist.irecv, _wire(got), 0), dist.P2POp(dist.isend, _wire(band), 0)]
-    for q in dist.batch_isend_irecv(ops):
-        q.wait()
-    torch.cuda.synchronize()
-    same = bool(torch.equal(got.view(torch.uint8), band.view(torch.uint8)))
-    print("bytes round trip equal:", same)
     dist.destroy_process_group()
     print("WIRE OK" if same else "WIRE FAIL")
     return 0 if same else 1
