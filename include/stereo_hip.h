@@ -97,6 +97,15 @@ int stx_synchronize(stx_ctx *ctx);
  * outputs; this exists for testing and benchmarking. */
 int stx_set_match_algo(stx_ctx *ctx, int algo);
 
+/* Diagnostics of the context's last stx_match* call that went through the MFMA prefilter
+ * ("the exact-replay overhead reported separately as candidates/query"): the sum and
+ * the maximum over the queries of the candidates the exact replay looked at, and the number of
+ * queries whose candidate lists overflowed and were re-scanned in full (Features.cpp:1036-1047
+ * over all of list2).  n_queries = 0 when the last call did not use the prefilter.  Waits for
+ * the context's stream.  No counterpart in the reference. */
+int stx_match_stats(stx_ctx *ctx, long long *total_candidates, int *max_candidates, int *overflow_queries,
+                    int *n_queries);
+
 /* Choose the D1-ext disparity kernel (STX_DISP_*).  Both give identical
  * outputs; this exists for testing and benchmarking. */
 int stx_set_disparity_algo(stx_ctx *ctx, int algo);

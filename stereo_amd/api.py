@@ -92,6 +92,17 @@ class Context:
     def set_match_algo(self, algo):
         check(self._lib.stx_set_match_algo(self._h, int(algo)), "stx_set_match_algo")
 
+    def match_stats(self):
+        """Candidates the exact replay looked at in the last prefilter call of this context:
+        {"queries", "candidates_total", "candidates_per_query", "candidates_max", "overflow_queries"}
+        (queries = 0 when the last matching call did not use the prefilter).  Waits for the stream."""
+        tot, mx, ov, nq = C.c_longlong(), C.c_int(), C.c_int(), C.c_int()
+        check(self._lib.stx_match_stats(self._h, C.byref(tot), C.byref(mx), C.byref(ov), C.byref(nq)),
+              "stx_match_stats")
+        return {"queries": nq.value, "candidates_total": tot.value,
+                "candidates_per_query": tot.value / nq.value if nq.value else 0.0,
+                "candidates_max": mx.value, "overflow_queries": ov.value}
+
     def set_disparity_algo(self, algo):
         check(self._lib.stx_set_disparity_algo(self._h, int(algo)), "stx_set_disparity_algo")
 

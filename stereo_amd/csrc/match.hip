@@ -8,6 +8,8 @@
 //   sqrt is the correctly rounded fp32 square root.
 //   closest = first j attaining the minimum of dist; second = the previous
 //   holder of the running minimum (first argmin over j < closest).
+#include <cstdlib>
+
 #include "stx_internal.h"
 
 namespace {
@@ -109,6 +111,155 @@ __global__ __launch_bounds__(EXACT_THREADS) void match_exact_kernel(
 
     float second_dist = -1.0f;
     if (second >= 0) second_dist = sqrtf(ref_norm2(a, desc2 + (size_t)second * K));  // :1064
+    if (closest_out) closest_out[i] = closest;
+    if (second_out) second_out[i] = second;
+    if (min_dist_out) min_dist_out[i] = min_dist;
+    if (second_dist_out) second_dist_out[i] = second_dist;
+    if (status_out)
+        status_out[i] = match_status(closest, second, min_dist, second_dist, score1[i], score2, dist_limit);
+}
+
+
+// ---------------------------------------------------------------------------
+// Overflow pass of the prefilter: the exact scan, cut along list2.
+//
+// A query whose candidate lists overflow must be scanned in full.  One lane per query (above) makes
+// that one dependent chain of n2 x 384 operations -- 0.4 s for ONE query at n2 = 200 000, next to a
+// 7.6 ms call.  Here a wave still holds 64 queries (rows arrive through the scalar data path, three
+// VALU operations per element: the scan runs at the VALU rate once the chip is full), but list2 is cut
+// into S contiguous segments scanned by S waves, S chosen ON THE DEVICE from the overflow count so
+// that the launch's OVF_WAVES waves are all busy: a handful of overflowing queries get thousands of
+// short segments, thousands of queries get a few long ones.
+//
+// A segment's scan is the reference's scan started from "no record yet" (Features.cpp:1035-1047) and
+// yields (closest_s, minDist_s, second_s, dist(second_s)).  The merge walks the segments in order.
+// The full scan's records inside segment s are exactly the segment's own records that beat the minimum
+// G held before it -- a suffix of the segment's strictly decreasing record chain -- so after a segment
+// with minDist_s < G:  closest = closest_s, and the previous record holder is second_s if it beat G
+// too, else the closest held before the segment.  Row 0 is taken unconditionally (minDist == -1), so a
+// NaN there sticks: no later `<` is ever true.  Rows after the first compare against +inf when the
+// segment has no record yet: a row at +inf or NaN is never a record there, and never one of the full
+// scan either (nothing is < a minimum that row 0 has already set).
+// ---------------------------------------------------------------------------
+constexpr int OVF_WAVES = 4096;      // waves per launch (4 per SIMD on 256 CUs)
+constexpr int OVF_MAX_SEGS = 2048;   // segments per query group at most
+
+struct OvfPartial {
+    int closest;
+    float min_dist;
+    int second;
+    float second_dist;
+};
+
+// the split the seg kernel and the merge kernel both derive from the overflow count
+__device__ __forceinline__ void ovf_split(int n_queries, int n2, int &groups, int &segs, int &rows_per_seg)
+{
+    groups = (n_queries + 63) / 64;
+    segs = groups > 0 ? OVF_WAVES / groups : 1;
+    segs = segs < 1 ? 1 : segs > OVF_MAX_SEGS ? OVF_MAX_SEGS : segs;
+    rows_per_seg = (n2 + segs - 1) / segs;
+    if (rows_per_seg < 16) rows_per_seg = 16;    // shorter segments only add merge steps
+    segs = (n2 + rows_per_seg - 1) / rows_per_seg;
+    if (segs < 1) segs = 1;
+}
+
+__global__ __launch_bounds__(64) void match_exact_seg_kernel(
+    const float *__restrict__ desc1, const float *__restrict__ desc2, int n2,
+    const int32_t *__restrict__ query_list, const int *__restrict__ n_queries_dev,
+    OvfPartial *__restrict__ partial)
+{
+    const int n_queries = *n_queries_dev;
+    if (n_queries <= 0) return;
+    int groups, segs, rows_per_seg;
+    ovf_split(n_queries, n2, groups, segs, rows_per_seg);
+    const int slots = OVF_WAVES / segs > 0 ? OVF_WAVES / segs : 1;  // query groups in flight
+    const int seg = blockIdx.x % segs;
+    if ((int)blockIdx.x >= slots * segs) return;
+    const int j_begin = seg * rows_per_seg;
+    const int j_end = j_begin + rows_per_seg < n2 ? j_begin + rows_per_seg : n2;
+#pragma unroll 1
+    for (int grp = blockIdx.x / segs; grp < groups; grp += slots) {
+        const int slot = grp * 64 + threadIdx.x;
+        const bool active = slot < n_queries;
+        // inactive lanes shadow the last query so that the row loop stays uniform
+        const int i = query_list[active ? slot : n_queries - 1];
+        float a[K];
+        const float4 *arow = reinterpret_cast<const float4 *>(desc1 + (size_t)i * K);
+#pragma unroll
+        for (int k = 0; k < K / 4; ++k) {
+            const float4 v = arow[k];
+            a[4 * k + 0] = v.x;
+            a[4 * k + 1] = v.y;
+            a[4 * k + 2] = v.z;
+            a[4 * k + 3] = v.w;
+        }
+        int closest = -1, second = -1;
+        float min_dist = __builtin_inff(), second_dist = -1.0f;
+        float min_norm2 = __builtin_inff();
+        for (int j = j_begin; j < j_end; ++j) {
+            const float *__restrict__ b = desc2 + (size_t)j * K;
+            float norm = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float d = a[k] - b[k];
+                const float sq = d * d;
+                norm = norm + sq;
+            }
+            if (j == 0) {  // minDist == -1 branch of :1041: taken whatever the value
+                closest = 0;
+                min_norm2 = norm;
+                min_dist = sqrtf(norm);
+            } else if (norm < min_norm2) {  // sqrt is monotonic: only then can dist be smaller
+                const float dist = sqrtf(norm);
+                if (dist < min_dist) {  // :1041
+                    second = closest;   // :1043
+                    second_dist = min_dist;
+                    closest = j;        // :1044
+                    min_dist = dist;    // :1045
+                    min_norm2 = norm;
+                }
+            }
+        }
+        if (active) {
+            OvfPartial r;
+            r.closest = closest;
+            r.min_dist = min_dist;
+            r.second = second;
+            r.second_dist = second_dist;
+            partial[(size_t)slot * segs + seg] = r;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void match_exact_merge_kernel(
+    const float *__restrict__ score1, const float *__restrict__ score2, int n2, float dist_limit,
+    const int32_t *__restrict__ query_list, const int *__restrict__ n_queries_dev,
+    const OvfPartial *__restrict__ partial, int32_t *__restrict__ closest_out, int32_t *__restrict__ second_out,
+    float *__restrict__ min_dist_out, float *__restrict__ second_dist_out, uint8_t *__restrict__ status_out)
+{
+    const int n_queries = *n_queries_dev;
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= n_queries) return;
+    int groups, segs, rows_per_seg;
+    ovf_split(n_queries, n2, groups, segs, rows_per_seg);
+    const int i = query_list[slot];
+    const OvfPartial *p = partial + (size_t)slot * segs;
+    // segment 0 holds row 0: the scan's state after it is the segment's own
+    int closest = p[0].closest, second = p[0].second;
+    float min_dist = p[0].min_dist, second_dist = p[0].second_dist;
+    for (int s = 1; s < segs; ++s) {
+        const OvfPartial r = p[s];
+        if (r.closest < 0 || !(r.min_dist < min_dist)) continue;  // no record of the full scan in this segment
+        if (r.second >= 0 && r.second_dist < min_dist) {          // its previous record holder was one too
+            second = r.second;
+            second_dist = r.second_dist;
+        } else {
+            second = closest;
+            second_dist = min_dist;
+        }
+        closest = r.closest;
+        min_dist = r.min_dist;
+    }
     if (closest_out) closest_out[i] = closest;
     if (second_out) second_out[i] = second;
     if (min_dist_out) min_dist_out[i] = min_dist;
@@ -1085,21 +1236,24 @@ __global__ __launch_bounds__(64) void match_replay_kernel(
             overflow |= c > subcap;
             count += c;
         }
-        if (overflow || count > MF_CAP) {  // too many near-ties: exact scan for this query
+        if (overflow) {  // a sub-list ran out of slots (too many near-ties): exact scan for this query
             if (l == 0) overflow_list[atomicAdd(overflow_count, 1)] = i;
             live = false;
         }
     }
     if (!live) count = 0;
-    if (live) {
+    // more candidates than the LDS arrays hold (but every sub-list complete): walked in place below
+    const bool in_lds = count <= MF_CAP;
+    if (live && in_lds) {
         for (int s = 0, base = 0; s < nsub; ++s) {
             const int c = cand_count[(size_t)i * nsub + s];
             const int *list = cand + ((size_t)i * nsub + s) * subcap;
             for (int p = l; p < c; p += RP_L) cj[base + p] = list[p];
             base += c;
         }
-        for (int k = l; k < K; k += RP_L) q[k] = desc1[(size_t)i * K + k];
     }
+    if (live)
+        for (int k = l; k < K; k += RP_L) q[k] = desc1[(size_t)i * K + k];
     __syncthreads();
     // Exact distances of the candidates, in any order.  The reference's scan over ascending j
     // (Features.cpp:1036-1047) needs no sort to replay: its `closest` is the first index of the
@@ -1113,9 +1267,7 @@ __global__ __launch_bounds__(64) void match_replay_kernel(
     float bd = inf, d0 = 0.0f;
     int bj = 0x7FFFFFFF;
     bool nan0 = false;
-#pragma unroll 1
-    for (int p = l; p < count; p += RP_L) {
-        const int j = cj[p];
+    auto exact_dist = [&](int j) {
         const float4 *b = reinterpret_cast<const float4 *>(desc2 + (size_t)j * K);
         float norm = 0.0f;
 #pragma unroll 8
@@ -1128,11 +1280,32 @@ __global__ __launch_bounds__(64) void match_replay_kernel(
             d = qv.z - bv.z; norm = norm + d * d;
             d = qv.w - bv.w; norm = norm + d * d;
         }
-        const float dt = sqrtf(norm);
-        dist[p] = dt;
-        if (j == 0) { nan0 = dt != dt; d0 = dt; }
-        const float dd = dt == dt ? dt : inf;
-        if (dd < bd || (dd == bd && j < bj)) { bd = dd; bj = j; }
+        return sqrtf(norm);
+    };
+    if (in_lds) {
+#pragma unroll 1
+        for (int p = l; p < count; p += RP_L) {
+            const int j = cj[p];
+            const float dt = exact_dist(j);
+            dist[p] = dt;
+            if (j == 0) { nan0 = dt != dt; d0 = dt; }
+            const float dd = dt == dt ? dt : inf;
+            if (dd < bd || (dd == bd && j < bj)) { bd = dd; bj = j; }
+        }
+    } else {
+#pragma unroll 1
+        for (int s = 0; s < nsub; ++s) {
+            const int c = cand_count[(size_t)i * nsub + s];
+            const int *list = cand + ((size_t)i * nsub + s) * subcap;
+#pragma unroll 1
+            for (int p = l; p < c; p += RP_L) {
+                const int j = list[p];
+                const float dt = exact_dist(j);
+                if (j == 0) { nan0 = dt != dt; d0 = dt; }
+                const float dd = dt == dt ? dt : inf;
+                if (dd < bd || (dd == bd && j < bj)) { bd = dd; bj = j; }
+            }
+        }
     }
     // reduce over the query's RP_L lanes (xor butterflies stay inside the aligned group)
 #pragma unroll
@@ -1158,13 +1331,30 @@ __global__ __launch_bounds__(64) void match_replay_kernel(
             min_dist = bd;
             float sd = inf;
             int sj = 0x7FFFFFFF;
+            if (in_lds) {
 #pragma unroll 1
-            for (int p = l; p < count; p += RP_L) {
-                const int j = cj[p];
-                if (j < closest) {
-                    const float dt = dist[p];
-                    const float dd = dt == dt ? dt : inf;
-                    if (dd < sd || (dd == sd && j < sj)) { sd = dd; sj = j; }
+                for (int p = l; p < count; p += RP_L) {
+                    const int j = cj[p];
+                    if (j < closest) {
+                        const float dt = dist[p];
+                        const float dd = dt == dt ? dt : inf;
+                        if (dd < sd || (dd == sd && j < sj)) { sd = dd; sj = j; }
+                    }
+                }
+            } else {  // long list: the distances of the candidates below `closest` once more
+#pragma unroll 1
+                for (int s = 0; s < nsub; ++s) {
+                    const int c = cand_count[(size_t)i * nsub + s];
+                    const int *list = cand + ((size_t)i * nsub + s) * subcap;
+#pragma unroll 1
+                    for (int p = l; p < c; p += RP_L) {
+                        const int j = list[p];
+                        if (j < closest) {
+                            const float dt = exact_dist(j);
+                            const float dd = dt == dt ? dt : inf;
+                            if (dd < sd || (dd == sd && j < sj)) { sd = dd; sj = j; }
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -1372,6 +1562,7 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
                      int32_t *d_closest, int32_t *d_second, float *d_min_dist,
                      float *d_second_dist, uint8_t *d_status)
 {
+    ctx->m_last_n1 = 0;  // stx_match_stats describes prefilter calls only
     if (n1 <= 0) return STX_OK;
     int algo = ctx->match_algo;
     if (algo == STX_MATCH_SMALL && n2 > 0)
@@ -1497,9 +1688,51 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
                        d_second_dist, d_status);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    // queries whose candidate list overflowed (count read on the device)
-    return launch_exact(ctx, d_desc1, d_score1, n1, d_desc2, d_score2, n2, dist_limit, ovf_list, ovf_count,
-                        d_closest, d_second, d_min_dist, d_second_dist, d_status);
+    ctx->m_last_counts = cnt;
+    ctx->m_last_overflow = ovf_count;
+    ctx->m_last_n1 = n1;
+    ctx->m_last_nsub = nsub;
+    // queries with an overflowed sub-list (count read on the device): the exact scan cut along list2
+    const size_t part_entries = (size_t)(n1 + 64 > 64 * OVF_WAVES ? n1 + 64 : 64 * OVF_WAVES);
+    OvfPartial *part = (OvfPartial *)stx_workspace(ctx, STX_SLOT_M_FALLBACK, sizeof(OvfPartial) * part_entries, &err);
+    if (!part) return err;
+    hipLaunchKernelGGL(match_exact_seg_kernel, dim3(OVF_WAVES), dim3(64), 0, st, d_desc1, d_desc2, n2, ovf_list,
+                       ovf_count, part);
+    hipLaunchKernelGGL(match_exact_merge_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_score1, d_score2, n2,
+                       dist_limit, ovf_list, ovf_count, part, d_closest, d_second, d_min_dist, d_second_dist, d_status);
+    return (int)hipGetLastError();
+}
+
+// Candidate statistics of the context's last prefilter call (diagnostics: SURVEY 8d asks for the
+// replay's cost as candidates per query).  Waits for the stream.
+int stx_match_stats_impl(stx_ctx *ctx, long long *total_candidates, int *max_candidates, int *overflow_queries,
+                         int *n_queries)
+{
+    *total_candidates = 0;
+    *max_candidates = *overflow_queries = *n_queries = 0;
+    if (!ctx->m_last_counts || ctx->m_last_n1 <= 0) return STX_OK;
+    const int n1 = ctx->m_last_n1, nsub = ctx->m_last_nsub;
+    int *h = (int *)malloc(sizeof(int) * ((size_t)n1 * nsub + 1));
+    if (!h) return STX_ERR_HOST_OOM;
+    hipError_t e = hipMemcpyAsync(h, ctx->m_last_counts, sizeof(int) * (size_t)n1 * nsub, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(h + (size_t)n1 * nsub, ctx->m_last_overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { free(h); return (int)e; }
+    long long tot = 0;
+    int mx = 0;
+    for (int i = 0; i < n1; ++i) {
+        int c = 0;
+        for (int s = 0; s < nsub; ++s) c += h[(size_t)i * nsub + s];
+        tot += c;
+        if (c > mx) mx = c;
+    }
+    *total_candidates = tot;
+    *max_candidates = mx;
+    *overflow_queries = h[(size_t)n1 * nsub];
+    *n_queries = n1;
+    free(h);
+    return STX_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -102,6 +102,14 @@ extern "C" int stx_set_match_algo(stx_ctx *ctx, int algo)
     return STX_OK;
 }
 
+extern "C" int stx_match_stats(stx_ctx *ctx, long long *total_candidates, int *max_candidates, int *overflow_queries,
+                               int *n_queries)
+{
+    if (!ctx || !total_candidates || !max_candidates || !overflow_queries || !n_queries) return STX_ERR_INVALID_ARG;
+    STX_ENTER(ctx);
+    return stx_match_stats_impl(ctx, total_candidates, max_candidates, overflow_queries, n_queries);
+}
+
 extern "C" int stx_set_disparity_algo(stx_ctx *ctx, int algo)
 {
     if (!ctx) return STX_ERR_INVALID_ARG;

@@ -49,6 +49,10 @@ struct stx_ctx {
     void *disp_scratch;
     size_t disp_scratch_bytes;
     int res_w[2], res_h[2];  // dimensions of the resident images (0: slot empty)
+    // the last prefilter call's candidate counters (stx_match_stats): device pointers into
+    // STX_SLOT_M_CAND, valid until the next matching call on this context
+    const int *m_last_counts, *m_last_overflow;
+    int m_last_n1, m_last_nsub;
     // Host-pointer entry points: pinned staging (grow-only), a second stream and events for
     // the chunked upload / compute / download pipeline, worker threads for the host copies.
     void *pin_ptr[2];  // [0] uploads, [1] downloads
@@ -151,6 +155,9 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
                      const float *d_desc2, const float *d_score2, int n2,
                      float dist_limit, int32_t *d_closest, int32_t *d_second,
                      float *d_min_dist, float *d_second_dist, uint8_t *d_status);
+
+int stx_match_stats_impl(stx_ctx *ctx, long long *total_candidates, int *max_candidates, int *overflow_queries,
+                         int *n_queries);
 
 int stx_launch_unpack_features(stx_ctx *ctx, const void *d_rec, int n, size_t stride, size_t desc_off,
                                size_t score_off, float *d_desc, float *d_score);

@@ -110,6 +110,35 @@ def descriptor_sets(seed, n1, n2):
     return d1, s1, d2, s2
 
 
+def descriptor_sets_clustered(seed, n1, n2, centres=2000, noise=1e-3, big_frac=0.005, big=2, with_clusters=False):
+    """(desc1, score1, desc2, score2) with repeated structure: every row of both lists is one of
+    `centres` SIFT-like descriptors plus N(0, noise^2) per component (clamped at 0, renormalised),
+    so a query has n2 / centres near-duplicates in list2 whose distances differ in the last digits
+    -- the case where near-ties pile up in the running-minimum scan (Features.cpp:1036-1047).  A
+    fraction `big_frac` of the rows of BOTH lists is dealt to the first `big` centres: those
+    queries see hundreds of near-ties (n2 * big_frac / big each), enough to overflow the
+    prefilter's candidate lists.  Rows are in random order; scores as descriptor_sets.
+    with_clusters: also return each row's centre (which1, which2)."""
+    c = sift_like(seed, centres).astype(np.float64)
+
+    def draw(sd, n):
+        which = (uniform01(sd, n) * centres).astype(np.int64)
+        if big > 0 and big_frac > 0:
+            isbig = uniform01(sd + 1, n) < big_frac
+            which = np.where(isbig, (uniform01(sd + 2, n) * big).astype(np.int64), which)
+        d = c[which] + noise * normal(sd + 3, n * 128).reshape(n, 128)
+        d = np.maximum(d, 0)
+        return (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32), which
+
+    d1, w1 = draw(seed + 1000, n1)
+    d2, w2 = draw(seed + 2000, n2)
+    s1 = (700 + 4300 * uniform01(seed + 300, n1)).astype(np.float32)
+    s2 = (700 + 4300 * uniform01(seed + 301, n2)).astype(np.float32)
+    if with_clusters:
+        return d1, s1, d2, s2, w1, w2
+    return d1, s1, d2, s2
+
+
 def homography(seed, w, h, deg_y=2.0, deg_x=0.5):
     """H = K R K^-1 (main.cpp:365) for a Middlebury-like K scaled to w x h."""
     f = 3979.911 * w / 2964.0

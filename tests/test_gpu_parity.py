@@ -710,6 +710,78 @@ def test_match_candidate_overflow_goes_to_exact_scan(ctx, oracle, algo):
     assert (want[0][:9] > n2 - 20).all()          # their nearest rows are the last ones
 
 
+@pytest.mark.parametrize("n1,n2,hot", [(70, 1500, 9), (5000, 1500, 5000), (300, 40000, 130), (9000, 3000, 4500)])
+def test_match_overflow_pass_cuts_list2_into_segments(ctx, oracle, n1, n2, hot):
+    """The overflow pass (match_exact_seg_kernel + match_exact_merge_kernel): `hot` queries sit next to a
+    vector that list2's rows approach steadily, so (almost) every row is a record for them and their
+    lists overflow.  The number of overflowing queries decides, on the device, how many segments
+    list2 is cut into (2048 short ones for a handful, one per wave for thousands), so both ends and
+    the middle are covered; NaN at row 0, +inf rows, and equal rows either side of segment borders
+    ride along."""
+    rng = np.random.RandomState(n1 + n2)
+    base = np.abs(rng.randn(128)).astype(np.float32)
+    base /= np.linalg.norm(base)
+    noise = np.abs(rng.randn(n2, 128)).astype(np.float32)
+    noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+    w = np.linspace(1.0, 0.01, n2, dtype=np.float32)[:, None]
+    d2 = (base[None, :] + w * noise).astype(np.float32)
+    d1 = np.abs(rng.randn(n1, 128)).astype(np.float32)
+    d1 /= np.linalg.norm(d1, axis=1, keepdims=True)
+    d1[:hot] = base[None, :] + 1e-3 * d1[:hot]
+    for k in range(10, n2 - 1, 97):
+        d2[k + 1] = d2[k]                      # equal rows: the first one stays (also across a border)
+    d2[n2 // 2, 7] = np.inf
+    d2[n2 - 3] = d2[n2 - 1]                    # the last record has an equal row before it
+    s1 = np.full(n1, 800, np.float32)
+    s2 = np.full(n2, 900, np.float32)
+    variants = [d2]
+    if n1 <= 300:
+        v = d2.copy(); v[0, 3] = np.nan        # NaN at row 0 sticks: nothing later is < NaN
+        variants.append(v)
+        v = d2.copy(); v[0, 3] = np.inf        # +inf at row 0: the first finite row takes over, second = 0
+        variants.append(v)
+    for v2 in variants:
+        ctx.set_match_algo(api.MATCH_MFMA_BF16X1)
+        try:
+            got = ctx.match(d1, s1, v2, s2, 1000.0)
+            st = ctx.match_stats()
+        finally:
+            ctx.set_match_algo(api.MATCH_AUTO)
+        assert st["queries"] == n1 and st["overflow_queries"] >= min(hot, 9), st
+        if n1 * n2 <= 3.0e7:
+            want = oracle.match(d1, s1, v2, s2, 1000.0)
+        else:
+            ctx.set_match_algo(api.MATCH_EXACT)
+            try:
+                want = ctx.match(d1, s1, v2, s2, 1000.0)
+            finally:
+                ctx.set_match_algo(api.MATCH_AUTO)
+            k = 140
+            _match_equal([g[:k] for g in want], oracle.match(d1[:k], s1[:k], v2, s2, 1000.0))
+        _match_equal(got, want)
+
+
+def test_match_long_candidate_lists_are_replayed_in_place(ctx, oracle):
+    """More candidates than the replay kernel's LDS arrays hold (256) but no sub-list overflow: a cluster
+    of ~315 near-identical rows spread over list2 lands in a query's four to six sub-lists, some 80
+    each (capacity 128 at this shape); the replay walks the lists in place and recomputes the
+    distances for `second`.  No query may take the overflow pass."""
+    n1, n2 = 66000, 9000
+    d1, s1, d2, s2 = synth.descriptor_sets_clustered(31, n1, n2, centres=200, noise=1e-3, big_frac=0.035, big=1)
+    ctx.set_match_algo(api.MATCH_MFMA_BF16X1)
+    try:
+        got = ctx.match(d1, s1, d2, s2, 1000.0)
+        st = ctx.match_stats()
+        ctx.set_match_algo(api.MATCH_EXACT)
+        want = ctx.match(d1, s1, d2, s2, 1000.0)
+    finally:
+        ctx.set_match_algo(api.MATCH_AUTO)
+    _match_equal(got, want)
+    assert st["candidates_max"] > 256 and st["overflow_queries"] == 0, st
+    idx = np.random.RandomState(3).choice(n1, 300, replace=False)
+    _match_equal([g[idx] for g in got], oracle.match(d1[idx], s1[idx], d2, s2, 1000.0))
+
+
 @pytest.mark.parametrize("n1,n2", [(513, 1300), (2100, 5000), (700, 33000), (9000, 40000)])
 def test_match_x1_pieces_and_padding(ctx, oracle, n1, n2):
     """Shapes that make the x1 kernel cut query blocks into several pieces, leave ragged last
