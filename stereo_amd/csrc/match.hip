@@ -1017,9 +1017,7 @@ __device__ __forceinline__ void x1_block(const uint4 (&f)[8], const bf16x8 (&qh0
         }
         if (s == 0) c = load_seeds(seeds, seeds_kb, half);
     }
-#ifndef X1_EXP_NO_CLOSE  // (timing experiments only)
     if (!FIRST) x1_close(p0, p1, b0, b1, live0, live1, jprev, half, n2, list0, list1, subcap);
-#endif
 #pragma unroll
     for (int s = 4; s < 8; ++s) {
         const bf16x8 fs = __builtin_bit_cast(bf16x8, f[s]);
@@ -1173,9 +1171,7 @@ __global__ __launch_bounds__(X1_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
             __builtin_amdgcn_sched_barrier(0);
             X1_BLOCK(false, fA, x0, x1, y0, y1, cur, 3, j0 + MF_JB);
             staged();         // this wave's share of tile tt + 1, issued one tile ago
-#ifndef X1_EXP_NO_BARRIER     // (timing experiments only: results are wrong without it)
             __syncthreads();  // tile tt + 1 has landed; nobody reads tile tt from LDS any more
-#endif
             if (tt + 2 < ntiles) stage(t_begin + tt + 2, cur);
             if (tt + 1 < ntiles) load_frag(oth + lane, fA);
             __builtin_amdgcn_sched_barrier(0);

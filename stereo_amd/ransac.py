@@ -78,7 +78,10 @@ def find_fundamental_matrix(p1, p2):
     f = vt[8].astype(f32)
     f = f / f32(np.sqrt(f32(np.dot(f, f))))
     fm = (t2.T @ f.reshape(3, 3) @ t1).astype(f32)
-    return True, (fm / fm[2, 2]).astype(f32)
+    # :158 divides by F(2,2) whatever it is: a hypothesis with F(2,2) = 0 comes out as inf / NaN,
+    # as in the reference, and is dropped by its callers' isfinite checks
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return True, (fm / fm[2, 2]).astype(f32)
 
 
 _W = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]], f32)
