@@ -71,7 +71,7 @@ extern "C" {
 /* disparity kernel selector (stx_set_disparity_algo) */
 #define STX_DISP_AUTO 0       /* register sliding-sum kernel (win <= 31, max_disp <= 4096), else the LDS column-sum kernel */
 #define STX_DISP_BRUTEFORCE 1 /* tap-by-tap kernel for every D1-ext call */
-#define STX_DISP_COLSUM 2     /* LDS column-sum kernel for windows 17x17 .. 31x31 (otherwise as AUTO) */
+#define STX_DISP_COLSUM 2     /* LDS column-sum kernel (what AUTO uses beyond 4096 disparities or 65535 columns) for every window */
 
 typedef struct stx_ctx stx_ctx;
 
@@ -105,6 +105,20 @@ int stx_set_match_algo(stx_ctx *ctx, int algo);
  * the context's stream.  No counterpart in the reference. */
 int stx_match_stats(stx_ctx *ctx, long long *total_candidates, int *max_candidates, int *overflow_queries,
                     int *n_queries);
+
+/* Device bytes the context currently holds in its grow-only workspace slots (staging, keys carried
+ * between passes, matching work lists ...).  Diagnostic; no counterpart in the reference. */
+size_t stx_workspace_bytes(const stx_ctx *ctx);
+
+/* How the host-pointer entry points would treat the caller's buffer [p, p + bytes):
+ *   0  pageable (or not inside ONE page-locked allocation the HIP runtime knows): staged through the
+ *      library's pinned buffers;
+ *   1  page-locked: read / written by the DMA engines as it lies;
+ *   2  page-locked and visible to kernels on the context's device (hipHostMalloc, hipHostRegister with
+ *      a mapping on that device): small results may be stored into it by the kernels themselves.
+ * Negative: error.  Diagnostic; no counterpart in the reference (cv::Mat rows are pageable unless the
+ * caller installs a pinned cv::MatAllocator, main.cpp:362-369). */
+int stx_host_buffer_kind(stx_ctx *ctx, const void *p, size_t bytes);
 
 /* Choose the D1-ext disparity kernel (STX_DISP_*).  Both give identical
  * outputs; this exists for testing and benchmarking. */

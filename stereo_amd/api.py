@@ -92,6 +92,17 @@ class Context:
     def set_match_algo(self, algo):
         check(self._lib.stx_set_match_algo(self._h, int(algo)), "stx_set_match_algo")
 
+    def workspace_bytes(self):
+        """Device bytes held in the context's grow-only workspace slots."""
+        return int(self._lib.stx_workspace_bytes(self._h))
+
+    def host_buffer_kind(self, arr):
+        """0 pageable / 1 page-locked (DMA direct) / 2 page-locked and kernel-visible, for a numpy array's memory."""
+        a = np.asarray(arr)
+        rc = int(self._lib.stx_host_buffer_kind(self._h, C.c_void_p(a.ctypes.data), a.nbytes))
+        check(min(rc, 0), "stx_host_buffer_kind")
+        return rc
+
     def match_stats(self):
         """Candidates the exact replay looked at in the last prefilter call of this context:
         {"queries", "candidates_total", "candidates_per_query", "candidates_max", "overflow_queries"}
@@ -137,10 +148,18 @@ class Context:
         """match() on arrays of feature RECORDS (the reference's std::vector<Feature> layout):
         rec1 / rec2 are [n, stride_bytes] uint8 arrays (or structured arrays) holding the 128-float
         descriptor at desc_offset and the score at score_offset of every record."""
-        r1 = np.ascontiguousarray(rec1).view(np.uint8).reshape(len(rec1), -1)
-        r2 = np.ascontiguousarray(rec2).view(np.uint8).reshape(len(rec2), -1) if len(rec2) else np.zeros((0, r1.shape[1]), np.uint8)
-        if len(rec1) == 0:
+        def rows(rec):
+            a = np.ascontiguousarray(rec)
+            return a.view(np.uint8).reshape(len(a), -1) if len(a) else None   # (-1 cannot be inferred for 0 rows)
+
+        r1, r2 = rows(rec1), rows(rec2)
+        if r1 is None and r2 is None:
+            stride0 = np.asarray(rec1).dtype.itemsize * int(np.prod(np.asarray(rec1).shape[1:], dtype=np.int64))
+            r1 = r2 = np.zeros((0, max(stride0, 1)), np.uint8)
+        elif r1 is None:
             r1 = np.zeros((0, r2.shape[1]), np.uint8)
+        elif r2 is None:
+            r2 = np.zeros((0, r1.shape[1]), np.uint8)
         if r1.shape[1] != r2.shape[1]:
             raise ValueError("both lists must use the same record size")
         n1, n2, stride = r1.shape[0], r2.shape[0], r1.shape[1]

@@ -1194,7 +1194,7 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
     const bool ssd = cost_mode == STX_COST_SSD && r > 0;  // a single tap orders candidates as SAD does
     // (the band kernel addresses an image through 32-bit buffer offsets: one image below 2 GiB)
     const bool band_ok = D <= 4096 && w < 65536 && !ctx->force_bruteforce && (unsigned long long)stride * (unsigned)h < (1ull << 31);
-    if (band_ok && r <= 15 && !(ctx->force_colsum && r > 7)) {
+    if (band_ok && r <= 15 && !ctx->force_colsum) {
         BandArgs a;
         a.img0 = d_img0; a.img1 = d_img1; a.w = w; a.h = h; a.stride = stride;
         a.pair_stride = pair_stride; a.row0 = row0; a.rows = rows; a.bh = rows; a.D = D;
@@ -1238,7 +1238,10 @@ int stx_launch_disparity(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_i
         default: return launch_band<15, false>(ctx, a, n_pairs, keys, keys_bytes);
         }
     }
-    if (r > 7 && r <= 15 && D <= 65536 && !ctx->force_bruteforce) {
+    // Beyond the register kernel's reach (more than 4096 disparities -- its 12-bit disparity code --,
+    // 65536 columns or more, an image of 2 GiB): the column-sum kernel, whose radius is a run-time
+    // value and whose passes of 256 disparities merge on the cost.  Every window 1x1 .. 31x31.
+    if (r <= 15 && D <= 65536 && !ctx->force_bruteforce) {
         ColsumArgs c;
         c.img0 = d_img0; c.img1 = d_img1; c.w = w; c.h = h; c.stride = stride; c.pair_stride = pair_stride;
         c.row0 = row0; c.rows = rows; c.bh = rows; c.r = r; c.D = D; c.dbase = 0; c.nd = 0; c.keys = nullptr;

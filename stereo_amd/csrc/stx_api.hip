@@ -102,6 +102,22 @@ extern "C" int stx_set_match_algo(stx_ctx *ctx, int algo)
     return STX_OK;
 }
 
+extern "C" size_t stx_workspace_bytes(const stx_ctx *ctx)
+{
+    size_t total = 0;
+    if (ctx)
+        for (int k = 0; k < STX_SLOT_COUNT; ++k) total += ctx->slot_bytes[k];
+    return total;
+}
+
+extern "C" int stx_host_buffer_kind(stx_ctx *ctx, const void *p, size_t bytes)
+{
+    if (!ctx) return STX_ERR_INVALID_ARG;
+    STX_ENTER(ctx);
+    if (!stx_host_is_pinned(p, bytes)) return 0;
+    return stx_host_kernel_ptr(p, bytes) ? 2 : 1;
+}
+
 extern "C" int stx_match_stats(stx_ctx *ctx, long long *total_candidates, int *max_candidates, int *overflow_queries,
                                int *n_queries)
 {

@@ -273,7 +273,10 @@ int stx_host_chunks(stx_ctx *ctx, size_t bytes, size_t units)
 
 // A caller whose buffers are already page-locked (hipHostMalloc, hipHostRegister, a pinned
 // cv::MatAllocator, torch pin_memory) needs no staging copy at all: the DMA engines read and write
-// its memory directly.  [p, p + bytes) must lie inside one registered allocation.
+// its memory directly.  [p, p + bytes) must lie inside ONE page-locked allocation the runtime knows:
+// both ends must be host memory and the runtime's address range around the first byte must hold the
+// last one too (two separate registrations that happen to be adjacent do not qualify; anything the
+// runtime cannot vouch for goes through the staging buffers, which is always correct).
 bool stx_host_is_pinned(const void *p, size_t bytes)
 {
     if (!p || bytes == 0) return false;
@@ -287,7 +290,37 @@ bool stx_host_is_pinned(const void *p, size_t bytes)
         (void)hipGetLastError();
         return false;
     }
-    return true;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess || !base) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const char *lo = (const char *)base, *q = (const char *)p;
+    return q >= lo && q + bytes <= lo + size;
+}
+
+// The address through which kernels on the CURRENT device may store into the page-locked host range
+// [p, p + bytes), or nullptr.  A registered range's device-visible address need not equal the host
+// address and need not exist on this device at all (hipHostRegister without the mapped / portable
+// flags, memory pinned for another GPU): the zero-copy paths use this address, never the raw host
+// pointer, and fall back to the staging buffer when there is none.
+void *stx_host_kernel_ptr(const void *p, size_t bytes)
+{
+    if (!stx_host_is_pinned(p, bytes)) return nullptr;
+    void *dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, const_cast<void *>(p), 0) != hipSuccess || !dev) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    // the last byte must map where the first one says it does
+    void *dev_end = nullptr;
+    if (hipHostGetDevicePointer(&dev_end, (char *)const_cast<void *>(p) + bytes - 1, 0) != hipSuccess ||
+        (char *)dev_end - (char *)dev != (ptrdiff_t)(bytes - 1)) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return dev;
 }
 
 // user rows -> pinned (workers) -> device (s_in), then ev is recorded on s_in.
@@ -338,9 +371,9 @@ static int fence_copy_streams(stx_ctx *ctx)
 // Disparity of output rows [row0, row0 + rows) of n_pairs pairs held in host memory; `out`
 // points at output row row0 of pair 0.  One pair: chunked over row bands (a band's scan starts
 // as soon as its rows and win/2 halo rows are resident).  A batch: chunked over groups of pairs.
-int stx_disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int n_pairs, int w, int h,
-                       size_t stride, size_t pair_stride, int row0, int rows, int win, int max_disp,
-                       int cost_mode, void *out, size_t out_stride, size_t out_pair_stride, int out_bytes)
+static int disparity_host_pipeline(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int n_pairs, int w, int h,
+                                   size_t stride, size_t pair_stride, int row0, int rows, int win, int max_disp,
+                                   int cost_mode, void *out, size_t out_stride, size_t out_pair_stride, int out_bytes)
 {
     if (n_pairs <= 0 || w <= 0 || rows <= 0) return STX_OK;
     const int r = max_disp == 0 ? 0 : win / 2;
@@ -417,7 +450,11 @@ int stx_disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, i
         // page-locked host memory, as the warp's destination is: no download to set up and wait for
         // (741x500: 0.165 -> 0.134 ms, 1080p: 0.29 -> 0.27 ms; at 5.7 MB the chunked download is as fast).
         const bool zc = oimg <= ((size_t)4 << 20) && stx_host_zero_copy_on();
-        uint8_t *ktarget = zc ? (out_direct ? o : pin_out) : dout;
+        // (kernels store through the device-visible address of the caller's page-locked rows, if this
+        // device has one; else through the staging buffer, copied out afterwards as for pageable rows)
+        uint8_t *o_dev = zc && out_direct ? (uint8_t *)stx_host_kernel_ptr(o, oimg) : nullptr;
+        const bool out_zc_direct = o_dev != nullptr;
+        uint8_t *ktarget = zc ? (out_zc_direct ? o_dev : pin_out) : dout;
         for (int c = 0; c < nc; ++c) {
             const int up_next = c == nc - 1 ? bh : (int)((long long)bh * (c + 1) / nc);
             const size_t ro = (size_t)up_prev * p, rn = (size_t)(up_next - up_prev);
@@ -453,7 +490,7 @@ int stx_disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, i
         if (zc) {
             for (int c = 0; c < nc; ++c) {
                 STX_HIP(hipEventSynchronize(ctx->ev_k[c]));
-                if (!out_direct && out_n[c] > 0)
+                if (!out_zc_direct && out_n[c] > 0)
                     pool_copy2d(ctx, o + (size_t)out_lo[c] * out_stride, out_stride, pin_out + (size_t)out_lo[c] * op, op, op,
                                 (size_t)out_n[c]);
             }
@@ -544,8 +581,8 @@ int stx_disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, i
 
 // One image through the warp (RectifyImage's loop): the source goes up in chunks, the kernel
 // runs once, destination row bands come back chunk by chunk.
-int stx_rectify_host(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h, size_t src_stride, uint8_t *dst,
-                     int dst_w, int dst_h, size_t dst_stride, const float Hinv[9], int flags, uint8_t *d_keep)
+static int rectify_host_pipeline(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h, size_t src_stride, uint8_t *dst,
+                                 int dst_w, int dst_h, size_t dst_stride, const float Hinv[9], int flags, uint8_t *d_keep)
 {
     int err;
     const size_t sp = (size_t)(src_w > 0 ? src_w : 1), dp = (size_t)dst_w;
@@ -610,11 +647,13 @@ int stx_rectify_host(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h, siz
     // kernel runs and there is no download to set up and wait for (1080p: 0.19 -> 0.16 ms; letting the
     // kernel READ the source from host memory as well was slower than the upload it saves).
     if (!preserve && !d_keep && dbytes <= ((size_t)4 << 20) && stx_host_zero_copy_on()) {
-        uint8_t *target = dst_direct ? dst : pin_out;
+        // the caller's rows through their device-visible address, if this device has one
+        uint8_t *dst_dev = dst_direct ? (uint8_t *)stx_host_kernel_ptr(dst, dbytes) : nullptr;
+        uint8_t *target = dst_dev ? dst_dev : pin_out;
         rc = stx_rectify_u8_dev(ctx, dsrc, src_w, src_h, sp, 0, target, dst_w, dst_h, dp, 0, Hinv, 1, flags);
         if (rc) return rc;
         STX_HIP(hipStreamSynchronize(ctx->stream));
-        if (!dst_direct) pool_copy2d(ctx, dst, dst_stride, pin_out, dp, dp, (size_t)dst_h);
+        if (!dst_dev) pool_copy2d(ctx, dst, dst_stride, pin_out, dp, dp, (size_t)dst_h);
         return STX_OK;
     }
     // destination row bands: kernel per band, download behind it
@@ -642,8 +681,9 @@ int stx_rectify_host(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h, siz
 
 // Scan of two images that are already on the device (dense, pitch == w); the map comes back in
 // row-band chunks, each band's download behind its kernel.
-int stx_disparity_resident_host(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_img1, int w, int h, int win,
-                                int max_disp, int cost_mode, void *out, size_t out_stride, int out_bytes)
+static int disparity_resident_host_pipeline(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_img1, int w, int h,
+                                            int win, int max_disp, int cost_mode, void *out, size_t out_stride,
+                                            int out_bytes)
 {
     int err;
     const size_t p = (size_t)w, op = p * (size_t)out_bytes, oimg = op * (size_t)h;
@@ -666,14 +706,17 @@ int stx_disparity_resident_host(stx_ctx *ctx, const uint8_t *d_img0, const uint8
     rc = fence_copy_streams(ctx);
     if (rc) return rc;
     uint8_t *pin_out = (uint8_t *)ctx->pin_ptr[1];
-    if (out_stride == op && stx_host_is_pinned(o, oimg)) pin_out = o;  // page-locked caller rows: direct
+    const bool o_pinned = out_stride == op && stx_host_is_pinned(o, oimg);
     if (oimg <= ((size_t)4 << 20) && stx_host_zero_copy_on()) {  // a small map: stored straight into pinned memory
-        rc = stx_launch_disparity(ctx, d_img0, d_img1, 1, w, h, p, 0, 0, h, win, max_disp, cost_mode, pin_out, op, 0,
-                                  out_bytes);
+        // (the caller's own page-locked rows through their device-visible address, if this device has one)
+        uint8_t *o_dev = o_pinned ? (uint8_t *)stx_host_kernel_ptr(o, oimg) : nullptr;
+        rc = stx_launch_disparity(ctx, d_img0, d_img1, 1, w, h, p, 0, 0, h, win, max_disp, cost_mode,
+                                  o_dev ? o_dev : pin_out, op, 0, out_bytes);
         if (rc) return rc;
         STX_HIP(hipEventRecord(ctx->ev_k[0], ctx->stream));
-        return stx_host_download_end(ctx, o, out_stride, pin_out, op, (size_t)h, ctx->ev_k[0]);
+        return stx_host_download_end(ctx, o, out_stride, o_dev ? o : pin_out, op, (size_t)h, ctx->ev_k[0]);
     }
+    if (o_pinned) pin_out = o;  // page-locked caller rows: the downloads land there directly
     const int nc = stx_host_chunks(ctx, oimg, (size_t)(h + 63) / 64);
     int lo[STX_HOST_MAX_CHUNKS], cnt[STX_HOST_MAX_CHUNKS];
     for (int c = 0; c < nc; ++c) {
@@ -693,6 +736,43 @@ int stx_disparity_resident_host(stx_ctx *ctx, const uint8_t *d_img0, const uint8
         if (rc) return rc;
     }
     return STX_OK;
+}
+
+// The pipelines above return at the first failing step.  By then earlier chunks' DMAs and kernels may
+// still be in flight on the three streams, aimed at the caller's buffers (direct and zero-copy paths)
+// and at the staging the next call reuses: a failed call drains them before it hands control back,
+// so the GPU never writes caller memory after the call has returned.
+static int drain_on_error(stx_ctx *ctx, int rc)
+{
+    if (rc == STX_OK) return rc;
+    if (ctx->s_in) (void)hipStreamSynchronize(ctx->s_in);
+    if (ctx->s_out) (void)hipStreamSynchronize(ctx->s_out);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipGetLastError();
+    return rc;
+}
+
+int stx_disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int n_pairs, int w, int h,
+                       size_t stride, size_t pair_stride, int row0, int rows, int win, int max_disp,
+                       int cost_mode, void *out, size_t out_stride, size_t out_pair_stride, int out_bytes)
+{
+    return drain_on_error(ctx, disparity_host_pipeline(ctx, img0, img1, n_pairs, w, h, stride, pair_stride, row0, rows,
+                                                       win, max_disp, cost_mode, out, out_stride, out_pair_stride,
+                                                       out_bytes));
+}
+
+int stx_rectify_host(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h, size_t src_stride, uint8_t *dst,
+                     int dst_w, int dst_h, size_t dst_stride, const float Hinv[9], int flags, uint8_t *d_keep)
+{
+    return drain_on_error(ctx, rectify_host_pipeline(ctx, src, src_w, src_h, src_stride, dst, dst_w, dst_h, dst_stride,
+                                                     Hinv, flags, d_keep));
+}
+
+int stx_disparity_resident_host(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_img1, int w, int h, int win,
+                                int max_disp, int cost_mode, void *out, size_t out_stride, int out_bytes)
+{
+    return drain_on_error(ctx, disparity_resident_host_pipeline(ctx, d_img0, d_img1, w, h, win, max_disp, cost_mode,
+                                                                out, out_stride, out_bytes));
 }
 
 // ------------------------------------------------------ flat arrays (M, ...) --

@@ -109,6 +109,7 @@ bool stx_host_zero_copy_on();  // kernels may store small results straight into 
 int stx_host_chunks(stx_ctx *ctx, size_t bytes, size_t units);
 int stx_host_fence(stx_ctx *ctx);
 bool stx_host_is_pinned(const void *p, size_t bytes);
+void *stx_host_kernel_ptr(const void *p, size_t bytes);  // device-visible address on the current device, or nullptr
 int stx_host_upload(stx_ctx *ctx, void *d_dst, void *pin, const void *src, size_t spitch, size_t wbytes,
                     size_t rows, hipEvent_t ev);
 int stx_host_download_begin(stx_ctx *ctx, void *pin, const void *d_src, size_t bytes, hipEvent_t after,

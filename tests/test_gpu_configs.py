@@ -337,6 +337,13 @@ def test_match_on_feature_records(ctx, oracle):
                 _match_equal(ctx.match_features(r1, r2, 20, 12, 1000.0), want)
             finally:
                 ctx.set_host_pipeline(True, 0, 0)
+    # n1 == 0 is a valid no-op, as for the C entry point and the drop-in, also with both lists empty
+    r2 = np.zeros(4, feature)
+    r2["desc"], r2["score"] = synth.sift_like(3, 4), 900.0
+    for empty2 in (r2, np.zeros(0, feature)):
+        got = ctx.match_features(np.zeros(0, feature), empty2, 20, 12, 1000.0)
+        assert all(len(g) == 0 for g in got)
+    r1 = np.zeros(5, feature)
     from stereo_amd import StereoHipError
     with pytest.raises(StereoHipError):
         ctx.match_features(r1, r1, 18, 12)      # misaligned descriptor offset
@@ -480,6 +487,93 @@ def test_page_locked_caller_buffers_skip_the_staging(ctx, oracle):
             assert (ctx.disparity_resident(0, 1, (h, w), out=po) == oracle.disparity_ref(wantr, wantr)).all()
         finally:
             ctx.set_host_pipeline(True, 0, 0)
+
+
+def test_page_locked_ranges_and_their_kernel_addresses(ctx, oracle):
+    """a caller buffer counts as page-locked only if the WHOLE range lies inside one
+    allocation the runtime knows (both ends being host memory is not enough), and kernels store
+    into it through its device-visible address, never the raw host pointer.
+    stx_host_buffer_kind says how a buffer would be treated; the calls give the oracle's bytes
+    whichever way it goes.  hipHostMalloc blocks through ctypes; hipHostRegister as well where the
+    box supports it (on this pool it returns hipErrorInvalidValue for any range, so that part
+    only runs elsewhere)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")      # the runtime already in the process
+    hip.hipHostMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+    hip.hipHostFree.argtypes = [ctypes.c_void_p]
+    hip.hipHostRegister.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint]
+    hip.hipHostUnregister.argtypes = [ctypes.c_void_p]
+    h, w = 300, 1024
+    n = h * w
+    l, r = synth.rectified_pair(41, h, w, 64)
+    src = synth.texture(42, h, w)
+    Hinv = oracle.invert3x3(synth.homography(5, w, h))
+    want = oracle.disparity_ext(l, r, 9, 64, 0, sliding=True)
+    want_top = oracle.disparity_ext(l[:h // 2], r[:h // 2], 9, 64, 0, sliding=True)
+    wantr = oracle.rectify(src, np.zeros_like(src), Hinv)
+    blocks = []
+
+    def host_block(nbytes):
+        p = ctypes.c_void_p()
+        assert hip.hipHostMalloc(ctypes.byref(p), nbytes, 0) == 0
+        blocks.append(p.value)
+        return np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(p.value))
+
+    def check_calls(pl, pr, po):
+        for on in (True, False):
+            ctx.set_host_pipeline(on, 0, 0)
+            try:
+                pl[...] = l
+                pr[...] = r
+                po[...] = 9
+                assert (ctx.disparity(pl, pr, win=9, max_disp=64, out=po) == want).all()
+                top = po[:h // 2]
+                top[...] = 9
+                assert (ctx.disparity(pl[:h // 2], pr[:h // 2], win=9, max_disp=64, out=top) == want_top).all()
+                pl[...] = src
+                top[...] = 3
+                ctx.rectify(pl, top, Hinv, api.RECT_DST_IS_ZERO)       # the kernel stores into the caller's rows
+                assert (top == wantr[:h // 2]).all()
+            finally:
+                ctx.set_host_pipeline(True, 0, 0)
+
+    try:
+        a = host_block(3 * n)
+        pl, pr, po = (a[k * n:(k + 1) * n].reshape(h, w) for k in range(3))
+        assert ctx.host_buffer_kind(a) == 2 and ctx.host_buffer_kind(po) == 2 and ctx.host_buffer_kind(po[7:9]) == 2
+        assert ctx.host_buffer_kind(np.zeros(n, np.uint8)) == 0                      # pageable
+        # one byte past the block's end: the last byte belongs to no (or another) allocation -> staged
+        past = np.ctypeslib.as_array((ctypes.c_uint8 * (n + 1)).from_address(blocks[0] + 2 * n))
+        b = host_block(n)                                                            # whatever lies behind block a now
+        assert ctx.host_buffer_kind(past) == 0
+        check_calls(pl, pr, po)
+        # registered memory (hipHostRegister): its device-visible address is what the kernels get
+        page = 4096
+        raw = np.zeros(4 * n + 2 * page, np.uint8)
+        off = (-raw.ctypes.data) % page
+        buf = raw[off:off + 4 * n]
+        half = (h // 2) * w
+        spans = [(0, n), (n, n), (2 * n, half), (2 * n + half, n - half)]            # the output rows: TWO registrations
+        regs = []
+        try:
+            for lo, cnt in spans:
+                if hip.hipHostRegister(buf[lo:].ctypes.data, cnt, 3) == 0:            # portable | mapped
+                    regs.append(buf[lo:].ctypes.data)
+            if len(regs) == len(spans):
+                rl, rr, ro = (buf[k * n:(k + 1) * n].reshape(h, w) for k in range(3))
+                assert ctx.host_buffer_kind(rl) >= 1 and ctx.host_buffer_kind(ro[:h // 2]) >= 1
+                assert ctx.host_buffer_kind(ro) == 0          # spans two registrations: staged
+                check_calls(rl, rr, ro)
+            else:
+                print("hipHostRegister unavailable on this box: registered-memory part not run")
+        finally:
+            ctx.synchronize()
+            for p_ in regs:
+                hip.hipHostUnregister(p_)
+    finally:
+        ctx.synchronize()
+        for p_ in blocks:
+            hip.hipHostFree(p_)
 
 
 def test_resident_rectified_images_feed_the_scan(ctx, oracle):

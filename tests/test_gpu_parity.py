@@ -175,6 +175,27 @@ def test_disparity_column_sum_kernel_forced(ctx, oracle, win, h, w, D, cm):
     assert (got == want).all(), np.argwhere(got != want)[:10]
 
 
+@pytest.mark.parametrize("win,cm,h,w,D", [(9, api.COST_SAD, 12, 5000, 4500), (3, api.COST_SSD, 9, 4300, 4200),
+                                          (1, api.COST_SAD, 5, 5000, 5000), (15, api.COST_SAD, 20, 4200, 4100),
+                                          (7, api.COST_SAD, 6, 300, 40), (5, api.COST_SSD, 30, 200, 200)])
+def test_disparity_small_windows_beyond_4096_disparities(ctx, oracle, win, cm, h, w, D):
+    """windows up to 15x15 with more than 4096 disparities used to be refused
+    (STX_ERR_TOO_LARGE: the register kernel's disparity code has 12 bits, the column-sum kernel took
+    only radii above 7).  The column-sum kernel's radius is a run-time value: it now takes every
+    window the register kernel cannot -- here through the size itself (D > 4096) and, for the small
+    cases, forced with STX_DISP_COLSUM."""
+    a, b = _rand_pair(win * 7 + h + w + D, h, w, zero=0.03)
+    dt = np.uint16 if D > 256 else np.uint8
+    want = oracle.disparity_ext(a, b, win, D, cm, dt, sliding=True)
+    if D <= 4096:
+        ctx.set_disparity_algo(api.DISP_COLSUM)
+    try:
+        got = ctx.disparity(a, b, win=win, max_disp=D, cost_mode=cm, out_dtype=dt)
+    finally:
+        ctx.set_disparity_algo(api.DISP_AUTO)
+    assert (got == want).all(), np.argwhere(got != want)[:10]
+
+
 @pytest.mark.parametrize("cm", [api.COST_SAD, api.COST_SSD])
 @pytest.mark.parametrize("win", [17, 31])
 def test_disparity_wide_windows_extreme_contrast(ctx, oracle, win, cm):

@@ -63,3 +63,38 @@ def test_no_alloc_disparity_matches_the_allocating_entry_point(ctx, oracle):
         assert torch.equal(o8, w8)
     finally:
         ctx.set_stream(0)
+
+
+def test_no_alloc_entry_point_allocates_nothing():
+    """The property the entry point exists for: on a FRESH context, calling only
+    stx_disparity_dev_noalloc -- two passes, so the keys carried between passes are in use -- leaves
+    the context's workspace at zero bytes and the device's free memory where it was."""
+    import torch
+    import stereo_amd
+    dev = torch.device("cuda", 0)
+    l, r = synth.rectified_pair(990, 200, 1100, 400)
+    a, b = torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev)
+    out = torch.zeros((200, 1100), dtype=torch.int16, device=dev)
+    want = torch.zeros((200, 1100), dtype=torch.int16, device=dev)
+    fresh = stereo_amd.Context(0)
+    try:
+        fresh.set_stream(torch.cuda.current_stream().cuda_stream)
+        assert fresh.workspace_bytes() == 0
+        # first call: one-time set-up of the kernel's LDS attribute (hipFuncSetAttribute, no memory)
+        fresh.disparity_dev_noalloc(a, b, out, win=9, max_disp=400)
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info(dev)
+        for _ in range(3):
+            fresh.disparity_dev_noalloc(a, b, out, win=9, max_disp=400)
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info(dev)
+        assert fresh.workspace_bytes() == 0
+        assert free1 == free0, (free0, free1)
+        # the allocating entry point, for contrast, takes its key buffer from the workspace
+        fresh.disparity_dev(a, b, want, win=9, max_disp=400)
+        torch.cuda.synchronize()
+        assert fresh.workspace_bytes() >= 200 * 1100 * 4
+        assert torch.equal(out, want)
+    finally:
+        fresh.set_stream(0)
+        fresh.close()
