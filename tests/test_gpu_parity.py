@@ -340,15 +340,37 @@ def test_disparity_dev_batch_and_rowband(ctx, oracle):
         ctx.set_stream(0)
 
 
+def _oracle_whole_map(oracle, l, r, win, D, dtype=np.uint8, threads=8):
+    """The sliding-sum oracle over the WHOLE image, as row bands with halo on a few host threads
+    (ctypes releases the GIL; a band plus win//2 halo rows gives the band's rows of the full map)."""
+    from concurrent.futures import ThreadPoolExecutor
+    h = l.shape[0]
+    halo = win // 2
+
+    def band(k):
+        lo, hi = k * h // threads, (k + 1) * h // threads
+        b0, b1 = max(0, lo - halo), min(h, hi + halo)
+        return oracle.disparity_ext(l[b0:b1], r[b0:b1], win, D, 0, dtype, sliding=True)[lo - b0:hi - b0]
+
+    with ThreadPoolExecutor(threads) as ex:
+        return np.concatenate(list(ex.map(band, range(threads))))
+
+
 def test_disparity_full_size_properties(ctx, oracle):
-    """BASELINE config 2 size (2880x1988): the oracle is run on sampled rows only
-    (the scan is row-local), plus two size-independent properties."""
+    """BASELINE config 2 at its own size (2880x1988): the WHOLE 9x9 / 256-disparity map against the
+    oracle (it was 15 sampled rows), reference mode on 64 rows spread over the image
+    (the scan is row-local; a reference-mode row costs the oracle W^2 comparisons), plus a
+    size-independent property."""
     h, w = 1988, 2880
     l, r = synth.rectified_pair(2024, h, w, 256)
     got = ctx.disparity(l, r)
-    rows = [0, 1, 997, 1986, 1987]
+    rows = sorted(set([0, 1, 997, 1986, 1987] + list(range(3, h, h // 60))))
+    assert len(rows) >= 64
     for y in rows:
-        assert (got[y] == oracle.disparity_ref(l[y:y + 1], r[y:y + 1])[0]).all()
+        assert (got[y] == oracle.disparity_ref(l[y:y + 1], r[y:y + 1])[0]).all(), y
+    gw_all = ctx.disparity(l, r, win=9, max_disp=256)
+    want_all = _oracle_whole_map(oracle, l, r, 9, 256)
+    assert (gw_all == want_all).all(), np.argwhere(gw_all != want_all)[:5]
     # property 1: the scan is row-local -- permuting rows permutes the output
     perm = np.random.RandomState(1).permutation(h)
     assert (ctx.disparity(l[perm], r[perm]) == got[perm]).all()
@@ -385,7 +407,8 @@ def test_config3_4k_512_disparities_rowbands(ctx, oracle):
     l, r = synth.rectified_pair(303, h, w, D)
     full = ctx.disparity(l, r, win=win, max_disp=D, out_dtype=np.uint16)
     assert full.max() > 255
-    _check_rows_against_oracle(full, l, r, win, D, [0, 1077, h - 4], np.uint16)
+    want = _oracle_whole_map(oracle, l, r, win, D, np.uint16)          # the whole 4K map, not sampled rows
+    assert (full == want).all(), np.argwhere(full != want)[:5]
     a, b = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
     out = torch.zeros(h, w, dtype=torch.int16, device="cuda")
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)

@@ -6,7 +6,8 @@ import stereo_amd
 from stereo_amd import synth, api
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
-d1, s1, d2, s2 = synth.descriptor_sets(42, n, n)
+clustered = len(sys.argv) > 2 and sys.argv[2] == "clustered"
+d1, s1, d2, s2 = synth.descriptor_sets_clustered(77, n, n) if clustered else synth.descriptor_sets(42, n, n)
 ctx = stereo_amd.Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 t = [torch.from_numpy(a).cuda() for a in (d1, s1, d2, s2)]
@@ -21,4 +22,4 @@ e0.record()
 for _ in range(10): f()
 e1.record(); torch.cuda.synchronize()
 print(os.path.basename(os.environ.get("STEREO_HIP_LIB", "default")), "ms/call %.3f" % (e0.elapsed_time(e1) / 10),
-      "accepted", int((ot == 3).sum().item()))
+      "accepted", int((ot == 3).sum().item()), ctx.match_stats())
