@@ -11,7 +11,8 @@ n = 200000
 d1, s1, d2, s2 = synth.descriptor_sets(42, n, n)
 t = [torch.from_numpy(a).cuda() for a in (d1, s1, d2, s2)]
 base = None
-for N in (1, 2, 4, 8):
+only = [int(a) for a in sys.argv[1:]]
+for N in (only or (1, 2, 4, 8)):
     n1 = n // N
     o = (torch.empty(n1, dtype=torch.int32, device="cuda"), torch.empty(n1, dtype=torch.int32, device="cuda"),
          torch.empty(n1, dtype=torch.float32, device="cuda"), torch.empty(n1, dtype=torch.float32, device="cuda"),
@@ -25,4 +26,5 @@ for N in (1, 2, 4, 8):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     base = base or ms
-    print("N = %d: %6d queries per GPU  %.3f ms  (ideal %.3f ms, efficiency %.2f)" % (N, n1, ms, base / N, base / N / ms))
+    print("N = %d: %6d queries per GPU  %.3f ms  (ideal %.3f ms, efficiency %.2f)  %s"
+          % (N, n1, ms, base / N, base / N / ms, ctx.match_stats()))
