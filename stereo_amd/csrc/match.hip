@@ -368,30 +368,11 @@ __global__ __launch_bounds__(256) void match_prep_frag_kernel(const float *__res
 }
 
 // squared norms (any summation order: covered by the error bound); padding rows get 0
-// seeds (x1 prefilter only, else nullptr): -|b_j|^2 / 2 per row (padding rows 0, unbounded rows +inf =
-// "-h" with h = -inf), written behind the fragments of the row's tile (tile_rows rows per tile of
-// tile_u4 uint4, the seeds seed_u4 uint4 into it)
 __global__ __launch_bounds__(256) void match_norm_kernel(const float *__restrict__ desc, int n, int npad,
-                                                         float *__restrict__ norm2, unsigned *__restrict__ max_bits,
-                                                         uint4 *__restrict__ seeds, int tile_rows, int tile_u4,
-                                                         int seed_u4)
+                                                         float *__restrict__ norm2)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
     float s = 0.f;
-    if (max_bits) {  // largest finite norm (bit pattern of a non-negative float orders as unsigned)
-        float v = 0.f;
-        if (r < n) {
-            const float4 *row = reinterpret_cast<const float4 *>(desc + (size_t)r * K);
-            for (int k = 0; k < K / 4; ++k) {
-                const float4 q = row[k];
-                v = fmaf(q.x, q.x, v); v = fmaf(q.y, q.y, v); v = fmaf(q.z, q.z, v); v = fmaf(q.w, q.w, v);
-            }
-            if (!(v <= 1e37f)) v = 0.f;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-        if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(max_bits, __float_as_uint(v));
-    }
     if (r >= npad) return;
     if (r < n) {
         const float4 *row = reinterpret_cast<const float4 *>(desc + (size_t)r * K);
@@ -406,12 +387,7 @@ __global__ __launch_bounds__(256) void match_norm_kernel(const float *__restrict
     }
     // keep sums of two norms finite; anything larger (or inf/NaN) becomes NaN, which the
     // prefilter treats as "cannot be bounded": the row / query is always a candidate
-    const float nv = s <= 1e37f ? s : __builtin_nanf("");
-    norm2[r] = nv;
-    if (seeds) {
-        float *sd = reinterpret_cast<float *>(seeds + (size_t)(r / tile_rows) * tile_u4 + seed_u4);
-        sd[r % tile_rows] = nv == nv ? -0.5f * nv : __builtin_inff();
-    }
+    norm2[r] = s <= 1e37f ? s : __builtin_nanf("");
 }
 
 __global__ __launch_bounds__(MF_WAVES * 64, 2) void match_mfma_kernel(
@@ -783,23 +759,81 @@ constexpr int MF_TILE_U4 = MF_TJ1 * 512 + 64;  // uint4 units per staged tile: f
 constexpr int X1_WAVES = 8;                    // waves per workgroup: one workgroup per CU, 2 waves per SIMD
 constexpr int X1_QB = X1_WAVES * MF_QW;        // queries per workgroup
 
-__global__ __launch_bounds__(256) void match_prep_frag_bf16x1_kernel(const float *__restrict__ desc2, int n2,
-                                                                     int n2pad, const float *__restrict__ bnorm,
-                                                                     uint4 *__restrict__ frag16)
+// list2's whole preparation for the x1 prefilter in ONE pass over the descriptors (round 2 used two
+// kernels that each read all of list2, the first with one lane per row, i.e. 64 rows and 64 cache
+// lines per load instruction: 107 + 24 us at 200 000 rows).  A workgroup takes one 32-row block; eight
+// lanes share a row, 16 consecutive floats each, so a wave reads 4 KiB of contiguous memory.  Per row:
+// the squared norm (any summation order: covered by the error bound; above 1e37 or non-finite -> NaN =
+// "cannot be bounded"), its seed -|b|^2 / 2 (+inf for an unbounded row) behind the fragments of the
+// row's tile, the bf16 fragments themselves (zeros for an unbounded or padding row), and the largest
+// finite norm of the block (match_max_kernel folds the blocks' maxima into the list's).
+__global__ __launch_bounds__(256) void match_prep_x1_kernel(const float *__restrict__ desc2, int n2, int n2pad,
+                                                            float *__restrict__ bnorm, float *__restrict__ block_max,
+                                                            uint4 *__restrict__ frag16)
 {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // one (jb, s, lane)
-    const size_t total = (size_t)n2pad / MF_JB * 8 * 64;
-    if (idx >= total) return;
-    const int lane = (int)(idx & 63);
-    const int s = (int)((idx >> 6) & 7);
-    const size_t jb = idx >> 9;
-    const size_t j = jb * MF_JB + (lane & 31);
-    uint4 hi = make_uint4(0, 0, 0, 0), lo;
-    if (j < (size_t)n2 && bnorm[j] == bnorm[j]) {  // unbounded rows (NaN norm) enter as zeros
-        const float4 *row = reinterpret_cast<const float4 *>(desc2 + j * K + 16 * s + 8 * (lane >> 5));
-        bf16_split8(row[0], row[1], hi, lo);
+    const int t = threadIdx.x;
+    const size_t jb = blockIdx.x;
+    const int rl = t >> 3, c = t & 7;           // row of the block, 16-float chunk of the row
+    const size_t j = jb * MF_JB + rl;
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < (size_t)n2) {
+        const float4 *row = reinterpret_cast<const float4 *>(desc2 + j * K + 16 * c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = row[i];
     }
-    frag16[(jb / MF_TJ1) * MF_TILE_U4 + (jb % MF_TJ1) * 512 + (idx & 511)] = hi;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s = fmaf(v[i].x, v[i].x, s);
+        s = fmaf(v[i].y, v[i].y, s);
+        s = fmaf(v[i].z, v[i].z, s);
+        s = fmaf(v[i].w, v[i].w, s);
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);                      // all eight lanes of the row hold its squared norm
+    const float nv = s <= 1e37f ? s : __builtin_nanf("");
+    float m = nv == nv ? nv : 0.f;              // largest finite norm: NaN rows enter no bound
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    // (no atomic on one word from 25 000 waves, not even a look at it first: the same-address traffic
+    // alone took 95 of this kernel's 119 us; the per-block maxima are folded by match_max_kernel)
+    __shared__ float wmax[4];
+    if ((t & 63) == 0) wmax[t >> 6] = m;
+    __syncthreads();
+    if (t == 0) block_max[jb] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    uint4 *tile = frag16 + (jb / MF_TJ1) * MF_TILE_U4;
+    if (c == 0) {
+        bnorm[j] = nv;                          // (j < n2pad: the grid is n2pad / 32 blocks)
+        reinterpret_cast<float *>(tile + MF_TJ1 * 512)[(jb % MF_TJ1) * MF_JB + rl] = nv == nv ? -0.5f * nv : __builtin_inff();
+    }
+    uint4 h0 = make_uint4(0, 0, 0, 0), h1 = h0, lo;
+    if (nv == nv) {                             // unbounded rows enter the matrix as zeros
+        bf16_split8(v[0], v[1], h0, lo);
+        bf16_split8(v[2], v[3], h1, lo);
+    }
+    // fragment order: frag16[tile][block][k-step s = c][lane = row + 32 * (upper 8 of the 16 floats)]
+    uint4 *dst = tile + (jb % MF_TJ1) * 512 + c * 64 + rl;
+    dst[0] = h0;
+    dst[32] = h1;
+}
+
+// largest finite squared norm of list2 from the per-block maxima (one workgroup; 0 if there is none)
+__global__ __launch_bounds__(1024) void match_max_kernel(const float *__restrict__ block_max, int n, float *__restrict__ out)
+{
+    __shared__ float part[16];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, block_max[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, part[i]);
+        *out = m;
+    }
 }
 
 // The first MF_WARM_ROWS rows of list2 are handled apart, per query, in fp32 (match_warm_kernel):
@@ -1604,9 +1638,12 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     int err;
     // [frag: n2pad*K floats, or x1 tiles of MF_TILE_U4 uint4][bnorm n2pad][bmax 1 (+pad)]
     const size_t frag_floats = x1 ? (size_t)tiles_total * MF_TILE_U4 * 4 : (size_t)n2pad * K;
-    float *frag = (float *)stx_workspace(ctx, STX_SLOT_M_FRAG, sizeof(float) * (frag_floats + (size_t)n2pad + 4), &err);
+    // (+ x1: the 32-row blocks' largest norms, n2pad / 32 floats)
+    float *frag = (float *)stx_workspace(ctx, STX_SLOT_M_FRAG,
+                                         sizeof(float) * (frag_floats + (size_t)n2pad + 4 + (size_t)n2pad / MF_JB), &err);
     if (!frag) return err;
     float *bnorm = frag + frag_floats;
+    float *block_max = bnorm + n2pad + 4;
     // [qnorm n1][ywarm n1]
     float *qnorm = (float *)stx_workspace(ctx, STX_SLOT_M_QNORM, sizeof(float) * 2 * (size_t)n1, &err);
     if (!qnorm) return err;
@@ -1649,22 +1686,25 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     if (!x1) STX_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (ncnt + 4), st));
     const bool bf16 = algo == STX_MATCH_MFMA_BF16;
     unsigned *bmax = reinterpret_cast<unsigned *>(bnorm + n2pad);
-    if (x1) STX_HIP(hipMemsetAsync(bmax, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL(match_norm_kernel, dim3((n2pad + 255) / 256), dim3(256), 0, st, d_desc2, n2, n2pad, bnorm,
-                       x1 ? bmax : (unsigned *)nullptr, x1 ? reinterpret_cast<uint4 *>(frag) : (uint4 *)nullptr,
-                       MF_TILE_ROWS1, MF_TILE_U4, MF_TJ1 * 512);
-    if (x1) {
-        hipLaunchKernelGGL(match_prep_frag_bf16x1_kernel, dim3((unsigned)(((size_t)n2pad / MF_JB * 512 + 255) / 256)),
-                           dim3(256), 0, st, d_desc2, n2, n2pad, bnorm, reinterpret_cast<uint4 *>(frag));
-    } else if (bf16)
+    if (x1)  // norms, seeds, fragments and the largest norm in one pass over list2
+    {
+        hipLaunchKernelGGL(match_prep_x1_kernel, dim3((unsigned)(n2pad / MF_JB)), dim3(256), 0, st, d_desc2, n2, n2pad,
+                           bnorm, block_max, reinterpret_cast<uint4 *>(frag));
+        hipLaunchKernelGGL(match_max_kernel, dim3(1), dim3(1024), 0, st, block_max, n2pad / MF_JB,
+                           reinterpret_cast<float *>(bmax));
+    }
+    else
+        hipLaunchKernelGGL(match_norm_kernel, dim3((n2pad + 255) / 256), dim3(256), 0, st, d_desc2, n2, n2pad, bnorm);
+    if (x1)
+        ;  // (fragments written above)
+    else if (bf16)
         hipLaunchKernelGGL(match_prep_frag_bf16_kernel, dim3((unsigned)(((size_t)n2pad / MF_JB * 512 + 255) / 256)),
                            dim3(256), 0, st, d_desc2, n2, n2pad, reinterpret_cast<uint4 *>(frag));
     else
         hipLaunchKernelGGL(match_prep_frag_kernel, dim3((unsigned)(((size_t)n2pad * K / 4 + 255) / 256)), dim3(256),
                            0, st, d_desc2, n2, n2pad, frag);
     if (!x1)
-        hipLaunchKernelGGL(match_norm_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_desc1, n1, n1, qnorm,
-                           (unsigned *)nullptr, (uint4 *)nullptr, 1, 0, 0);
+        hipLaunchKernelGGL(match_norm_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_desc1, n1, n1, qnorm);
     if (x1) {
         hipLaunchKernelGGL(match_warm_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d_desc1, qnorm, n1, d_desc2, n2,
                            bnorm, reinterpret_cast<const float *>(bmax), ywarm, nsub, subcap, cnt, cand, ovf_count);
