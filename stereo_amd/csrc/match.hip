@@ -15,6 +15,7 @@
 namespace {
 
 constexpr int K = STX_DESC_LEN;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // squared distance in the reference's operation order (the value L2_norm holds
 // in `norm` just before its sqrt, Features.cpp:809-813)
@@ -70,28 +71,29 @@ __global__ __launch_bounds__(EXACT_THREADS) void match_exact_kernel(
     const int qslot = active ? slot : n_queries - 1;
     const int i = query_list ? query_list[qslot] : qslot;
 
-    float a[K];
+    // differences and squares two elements at a time (packed fp32, rounded as the scalar instructions
+    // round), the sum one accumulator in ascending k: 4 vector instructions per two elements, not 6
+    f32x2 a[K / 2];
     const float4 *arow = reinterpret_cast<const float4 *>(desc1 + (size_t)i * K);
 #pragma unroll
     for (int k = 0; k < K / 4; ++k) {
         const float4 v = arow[k];
-        a[4 * k + 0] = v.x;
-        a[4 * k + 1] = v.y;
-        a[4 * k + 2] = v.z;
-        a[4 * k + 3] = v.w;
+        a[2 * k + 0] = f32x2{v.x, v.y};
+        a[2 * k + 1] = f32x2{v.z, v.w};
     }
 
     int closest = -1, second = -1;
     float min_dist = -1.0f;  // Features.cpp:1035
     float min_norm2 = 0.0f;
     for (int j = 0; j < n2; ++j) {
-        const float *__restrict__ b = desc2 + (size_t)j * K;
+        const f32x2 *__restrict__ b = reinterpret_cast<const f32x2 *>(desc2 + (size_t)j * K);
         float norm = 0.0f;
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float d = a[k] - b[k];
-            const float sq = d * d;
-            norm = norm + sq;
+        for (int k = 0; k < K / 2; ++k) {
+            const f32x2 d = a[k] - b[k];
+            const f32x2 sq = d * d;
+            norm = norm + sq.x;
+            norm = norm + sq.y;
         }
         if (j == 0) {  // minDist == -1 branch of :1041
             closest = 0;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void match_exact_kernel(
     if (!active) return;
 
     float second_dist = -1.0f;
-    if (second >= 0) second_dist = sqrtf(ref_norm2(a, desc2 + (size_t)second * K));  // :1064
+    if (second >= 0) second_dist = sqrtf(ref_norm2(reinterpret_cast<const float *>(a), desc2 + (size_t)second * K));  // :1064
     if (closest_out) closest_out[i] = closest;
     if (second_out) second_out[i] = second;
     if (min_dist_out) min_dist_out[i] = min_dist;
@@ -183,27 +185,30 @@ __global__ __launch_bounds__(64) void match_exact_seg_kernel(
         const bool active = slot < n_queries;
         // inactive lanes shadow the last query so that the row loop stays uniform
         const int i = query_list[active ? slot : n_queries - 1];
-        float a[K];
+        // the query as 64 pairs: differences and squares of two elements at a time are packed fp32
+        // operations (v_pk_add_f32, v_pk_mul_f32: each lane's two results rounded exactly as the scalar
+        // instructions round them); the sum stays ONE accumulator, k ascending -- 4 vector
+        // instructions per two elements instead of 6
+        f32x2 a[K / 2];
         const float4 *arow = reinterpret_cast<const float4 *>(desc1 + (size_t)i * K);
 #pragma unroll
         for (int k = 0; k < K / 4; ++k) {
             const float4 v = arow[k];
-            a[4 * k + 0] = v.x;
-            a[4 * k + 1] = v.y;
-            a[4 * k + 2] = v.z;
-            a[4 * k + 3] = v.w;
+            a[2 * k + 0] = f32x2{v.x, v.y};
+            a[2 * k + 1] = f32x2{v.z, v.w};
         }
         int closest = -1, second = -1;
         float min_dist = __builtin_inff(), second_dist = -1.0f;
         float min_norm2 = __builtin_inff();
         for (int j = j_begin; j < j_end; ++j) {
-            const float *__restrict__ b = desc2 + (size_t)j * K;
+            const f32x2 *__restrict__ b = reinterpret_cast<const f32x2 *>(desc2 + (size_t)j * K);
             float norm = 0.0f;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const float d = a[k] - b[k];
-                const float sq = d * d;
-                norm = norm + sq;
+            for (int k = 0; k < K / 2; ++k) {
+                const f32x2 d = a[k] - b[k];
+                const f32x2 sq = d * d;
+                norm = norm + sq.x;
+                norm = norm + sq.y;
             }
             if (j == 0) {  // minDist == -1 branch of :1041: taken whatever the value
                 closest = 0;
