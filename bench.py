@@ -536,7 +536,10 @@ def main():
             torch.cuda.synchronize()
             leg["gathered_equals_single_gpu_map"] = bool(torch.equal(gathered[0].to(ref3.device), ref3))
             if world == 1:
-                leg["roofline"] = valu_roofline(counters, "disp_band_9x9_sad_d512_3840x2160", u3, OPS_PER_UNIT_WINDOWED, ms_c)
+                k3 = event_time_ms(torch, band_step, 10, 0)      # two launches (passes of 256 disparities) per call
+                leg["kernel_ms"] = k3
+                leg["roofline"] = valu_roofline(counters, "disp_band_9x9_sad_d512_3840x2160", u3, OPS_PER_UNIT_WINDOWED, k3,
+                                                "disp_band_kernel<4,false> x 2 passes")
             extra["disparity_config3_4k_d512"] = leg
             del ref3
         del t_l3, t_r3, band_out
@@ -582,7 +585,11 @@ def main():
             leg["gathered_equals_single_pair_maps"] = bool(
                 (g.view(n4 // distinct, distinct, h4, w4) == single4.unsqueeze(0)).all().item())
             if world == 1:
-                leg["roofline"] = valu_roofline(counters, "disp_band_9x9_sad_d192_1024x1080p", u4, OPS_PER_UNIT_WINDOWED, ms_c)
+                # one launch per call: HIP events around two calls give the kernel time (ms_compute is wall clock)
+                k4 = event_time_ms(torch, batch_step, 2, 0)
+                leg["kernel_ms"] = k4
+                leg["roofline"] = valu_roofline(counters, "disp_band_9x9_sad_d192_1024x1080p", u4, OPS_PER_UNIT_WINDOWED, k4,
+                                                "disp_band_kernel<4,false>, grid z = 1024 pairs")
             extra["disparity_config4_batch1024"] = leg
             del single4, g
         gathered[0] = None

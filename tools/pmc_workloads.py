@@ -1,7 +1,7 @@
 """Runs the kernels bench.py times, one workload after the other in a fixed order, so that a
 rocprofv3 --pmc pass over THIS script can be cut into per-workload counters by
 tools/pmc_collect.py (same inputs, seeds and sizes as bench.py).  Writes the order it ran in to
-gpurun_out/pmc_r02/workloads.json.
+gpurun_out/pmc_r03/workloads.json (PMC_OUT overrides the directory).
 
     rocprofv3 --pmc <counters> --kernel-trace --output-format csv -d <dir> -o p -- python3 tools/pmc_workloads.py
 """
@@ -53,6 +53,16 @@ t_o3 = torch.empty((h3, w3), dtype=torch.int16, device="cuda")
 run("disp_band_9x9_sad_d512_3840x2160", "disp_band_kernel<4, false>", 2,
     lambda: ctx.disparity_dev(t_l3, t_r3, t_o3, win=WIN, max_disp=D3))
 del t_l3, t_r3, t_o3
+# BASELINE config 4: 1024 pairs of 1080p, 192 disparities, one batched launch (four distinct pairs repeated)
+w4, h4, D4, n4, distinct = 1920, 1080, 192, 1024, 4
+p4 = [synth.rectified_pair(400 + k, h4, w4, D4) for k in range(distinct)]
+d_l4 = torch.from_numpy(np.stack([p[0] for p in p4])).cuda().repeat(n4 // distinct, 1, 1)
+d_r4 = torch.from_numpy(np.stack([p[1] for p in p4])).cuda().repeat(n4 // distinct, 1, 1)
+t_o4 = torch.empty_like(d_l4)
+run("disp_band_9x9_sad_d192_1024x1080p", "disp_band_kernel<4, false>", 1,
+    lambda: ctx.disparity_dev(d_l4, d_r4, t_o4, win=WIN, max_disp=D4), calls=2)
+del d_l4, d_r4, t_o4
+torch.cuda.empty_cache()
 nimg, rh, rw = 8, 1080, 1920
 src = torch.from_numpy(np.stack([synth.texture(70 + k, rh, rw) for k in range(2)])).cuda().repeat(nimg // 2, 1, 1).contiguous()
 dstt = torch.zeros_like(src)
@@ -90,7 +100,17 @@ ot = torch.empty(n, dtype=torch.uint8, device="cuda")
 run("match_x1_prefilter_200k", "match_mfma_bf16x1_kernel", 1,
     lambda: ctx.match_dev(t[0], t[1], t[2], t[3], 1000.0, oc, os_, om, od, ot))
 order.append({"key": "match_replay_200k", "kernel": "match_replay_kernel", "launches_per_call": 1, "calls": CALLS})
-out = os.path.join(ROOT, "gpurun_out", "pmc_r02")
+order.append({"key": "match_prep_200k", "kernel": "match_prep_x1_kernel", "launches_per_call": 1, "calls": CALLS})
+order.append({"key": "match_warm_200k", "kernel": "match_warm_kernel", "launches_per_call": 1, "calls": CALLS})
+order.append({"key": "match_overflow_scan_200k", "kernel": "match_exact_seg_kernel", "launches_per_call": 1, "calls": CALLS})
+# the same size on descriptors with repeated structure (near-ties, overflowing queries)
+c1, cs1, c2, cs2 = synth.descriptor_sets_clustered(77, n, n)
+tc = [torch.from_numpy(a).cuda() for a in (c1, cs1, c2, cs2)]
+run("match_x1_prefilter_200k_clustered", "match_mfma_bf16x1_kernel", 1,
+    lambda: ctx.match_dev(tc[0], tc[1], tc[2], tc[3], 1000.0, oc, os_, om, od, ot))
+order.append({"key": "match_replay_200k_clustered", "kernel": "match_replay_kernel", "launches_per_call": 1, "calls": CALLS})
+order.append({"key": "match_overflow_scan_200k_clustered", "kernel": "match_exact_seg_kernel", "launches_per_call": 1, "calls": CALLS})
+out = os.environ.get("PMC_OUT") or os.path.join(ROOT, "gpurun_out", "pmc_r03")
 os.makedirs(out, exist_ok=True)
 json.dump(order, open(os.path.join(out, "workloads.json"), "w"), indent=1)
 print("ran", len(order), "workloads")
