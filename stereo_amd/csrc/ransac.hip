@@ -71,6 +71,84 @@ __device__ __forceinline__ float col_dot3_seq(const float *m, int c, float v0, f
     return s;
 }
 
+// ---- divisions ----------------------------------------------------------------------------
+// Triangulate and ReprojectionError divide whole vectors by one scalar (x / x(2), u / |u|, ...):
+// 15 of the kernel's 20 divisions share a denominator with one or two others, and three of them
+// are x / x.  The compiler's expansion of an IEEE fp32 divide on gfx950 is v_div_scale x2, v_rcp, a
+// Newton step on the reciprocal, two residual corrections of the quotient, v_div_fmas, v_div_fixup.
+// When |n| and |d| lie in [2^-40, 2^40] neither v_div_scale rescales anything, v_div_fmas is a plain
+// fma and v_div_fixup returns its input, so the same fma chain without those three instructions gives
+// the same bits (the argument and the guard of divide_pair in rectify.hip, whose test walks the
+// guard's limits); the reciprocal and its Newton step are shared, two chains run as packed fp32.
+// Lanes outside the range take the compiler's full divide.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bool div_in_range(float lo, float hi) { return lo >= 0x1p-40f && hi <= 0x1p40f; }
+
+__device__ __forceinline__ float shared_rcp(float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+
+__device__ __forceinline__ f32x2 quot2(f32x2 n, float d, float r)
+{
+    const f32x2 nd = {-d, -d}, rr = {r, r};
+    f32x2 t = n * rr;
+    f32x2 res = __builtin_elementwise_fma(nd, t, n);
+    t = __builtin_elementwise_fma(res, rr, t);
+    res = __builtin_elementwise_fma(nd, t, n);
+    return __builtin_elementwise_fma(res, rr, t);
+}
+
+__device__ __forceinline__ float quot1(float n, float d, float r)
+{
+    float t = n * r;
+    float res = __builtin_fmaf(-d, t, n);
+    t = __builtin_fmaf(res, r, t);
+    res = __builtin_fmaf(-d, t, n);
+    return __builtin_fmaf(res, r, t);
+}
+
+// n0 / d and n1 / d, correctly rounded
+__device__ __forceinline__ void divide2(float &n0, float &n1, float d)
+{
+    const float a0 = fabsf(n0), a1 = fabsf(n1), ad = fabsf(d);
+    if (div_in_range(fminf(fminf(a0, a1), ad), fmaxf(fmaxf(a0, a1), ad))) {
+        const f32x2 q = quot2(f32x2{n0, n1}, d, shared_rcp(d));
+        n0 = q.x;
+        n1 = q.y;
+    } else {
+        n0 = n0 / d;
+        n1 = n1 / d;
+    }
+}
+
+// n0 / d, n1 / d and n2 / d, correctly rounded
+__device__ __forceinline__ void divide3(float &n0, float &n1, float &n2, float d)
+{
+    const float a0 = fabsf(n0), a1 = fabsf(n1), a2 = fabsf(n2), ad = fabsf(d);
+    if (div_in_range(fminf(fminf(a0, a1), fminf(a2, ad)), fmaxf(fmaxf(a0, a1), fmaxf(a2, ad)))) {
+        const float r = shared_rcp(d);
+        const f32x2 q = quot2(f32x2{n0, n1}, d, r);
+        n0 = q.x;
+        n1 = q.y;
+        n2 = quot1(n2, d, r);
+    } else {
+        n0 = n0 / d;
+        n1 = n1 / d;
+        n2 = n2 / d;
+    }
+}
+
+// x / x: exactly 1 for every finite non-zero x (denormals included: the quotient of equal numbers is
+// representable, so the correctly rounded result is it), NaN for 0, +-inf and NaN
+__device__ __forceinline__ float self_quotient(float x)
+{
+    return (x - x == 0.0f && x != 0.0f) ? 1.0f : __builtin_nanf("");
+}
+
 __global__ __launch_bounds__(RS_THREADS) void ransac_error_kernel(
     const float *__restrict__ rec, Cams cams, const float2 *__restrict__ p1, const float2 *__restrict__ p2, int n,
     float *__restrict__ errors, float2 *__restrict__ depths)
@@ -134,17 +212,17 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_error_kernel(
     bool ok = r[33] != 0.0f;
     float d0 = nanv, d1 = nanv;
     if (ok) {
-        const float nx0 = x0 / x2, nx1 = x1 / x2, nx2 = x2 / x2;
-        float v0 = y0 / y2, v1 = y1 / y2, v2 = y2 / y2;
+        float nx0 = x0, nx1 = x1;
+        divide2(nx0, nx1, x2);
+        const float nx2 = self_quotient(x2);
+        float v0 = y0, v1 = y1;
+        divide2(v0, v1, y2);
+        float v2 = self_quotient(y2);
         float u0 = row_dot3(Rt, 0, nx0, nx1, nx2), u1 = row_dot3(Rt, 1, nx0, nx1, nx2),
               u2 = row_dot3(Rt, 2, nx0, nx1, nx2);
         const float un = sqrtf(dot3(u0, u1, u2, u0, u1, u2)), vn = sqrtf(dot3(v0, v1, v2, v0, v1, v2));
-        u0 = u0 / un;
-        u1 = u1 / un;
-        u2 = u2 / un;
-        v0 = v0 / vn;
-        v1 = v1 / vn;
-        v2 = v2 / vn;
+        divide3(u0, u1, u2, un);
+        divide3(v0, v1, v2, vn);
         const float a = dot3(u0, u1, u2, tt[0], tt[1], tt[2]), b = dot3(u0, u1, u2, u0, u1, u2),
                     c = dot3(u0, u1, u2, v0, v1, v2), d = dot3(v0, v1, v2, tt[0], tt[1], tt[2]),
                     e = dot3(v0, v1, v2, v0, v1, v2);
@@ -171,9 +249,8 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_error_kernel(
     float t1 = row_dot3(Rinv, 1, s0, s1, s2) - Rinvt[1];
     float t2 = row_dot3(Rinv, 2, s0, s1, s2) - Rinvt[2];
     const float z = t2;
-    t0 = t0 / z;
-    t1 = t1 / z;
-    t2 = t2 / z;
+    divide2(t0, t1, z);
+    t2 = self_quotient(z);
     const float w0 = row_dot3(cams.k2, 0, t0, t1, t2) - a1.x, w1 = row_dot3(cams.k2, 1, t0, t1, t2) - a1.y,
                 w2 = row_dot3(cams.k2, 2, t0, t1, t2) - 1.0f;
     errors[o] = sqrtf(dot3(w0, w1, w2, w0, w1, w2));

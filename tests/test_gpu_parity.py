@@ -1227,6 +1227,33 @@ def test_ransac_score_degenerate_records(ctx, oracle):
     assert (want[2][1] == 1000).all() and want[0][1] == 130   # threshold inf: every pair counts
 
 
+def test_ransac_score_division_ranges(ctx, oracle):
+    """The error kernel divides vectors by a scalar with a shared reciprocal when all operands lie in
+    [2^-40, 2^40] and with the full IEEE divide otherwise (ransac.hip, divide2 / divide3), and takes
+    x / x as 1 for finite non-zero x.  Camera matrices and the hypotheses' translations scaled by 2^k
+    push x(2), |u|, |v| and the reprojection's z across the guard's limits, into the v_div_scale
+    ranges and the denormals; every error and depth must stay the oracle's, bit for bit."""
+    from stereo_amd import synth
+    k1, k2, p1, p2, fm = synth.two_view_matches(31, 700)
+    recs, excl = _hypotheses(p1, p2, k1, k2, fm, 5, 700)
+    two = np.float32(2.0)
+    for k in (-120, -100, -64, -41, -40, -39, -20, 0, 20, 39, 40, 41, 64, 100, 120):
+        sc = two ** np.float32(k) if abs(k) < 127 else None
+        for what in ("cameras", "translation", "both"):
+            a1, a2, r = k1.copy(), k2.copy(), recs.copy()
+            if what in ("cameras", "both"):
+                a1 = (a1 * sc).astype(np.float32)           # K1^-1 p scales by 2^-k: x(2) = 2^-k
+                a2 = (a2 / sc).astype(np.float32)
+            if what in ("translation", "both"):
+                r[:, 30:33] = r[:, 30:33] * sc               # t' (and with it the depths, s, t and z)
+                r[:, 18:21] = r[:, 18:21] * sc               # R^-1 t
+            with np.errstate(all="ignore"):
+                want = oracle.ransac_score(r, a1, a2, p1, p2, excl)
+                got = ctx.ransac_score(r, a1, a2, p1, p2, exclude=excl, want_errors=True, want_depths=True)
+            assert np.array_equal(got[0], want[0]), (k, what)
+            assert _same_f32(got[1], want[1]) and _same_f32(got[2], want[2]) and _same_f32(got[3], want[3]), (k, what)
+
+
 def test_ransac_score_empty_inputs(ctx):
     k = np.eye(3, dtype=np.float32)
     inl, tot = ctx.ransac_score(np.zeros((0, 36), np.float32), k, k, np.zeros((5, 2)), np.zeros((5, 2)))
