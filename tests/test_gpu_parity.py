@@ -1241,12 +1241,13 @@ def test_ransac_score_division_ranges(ctx, oracle):
         sc = two ** np.float32(k) if abs(k) < 127 else None
         for what in ("cameras", "translation", "both"):
             a1, a2, r = k1.copy(), k2.copy(), recs.copy()
-            if what in ("cameras", "both"):
-                a1 = (a1 * sc).astype(np.float32)           # K1^-1 p scales by 2^-k: x(2) = 2^-k
-                a2 = (a2 / sc).astype(np.float32)
-            if what in ("translation", "both"):
-                r[:, 30:33] = r[:, 30:33] * sc               # t' (and with it the depths, s, t and z)
-                r[:, 18:21] = r[:, 18:21] * sc               # R^-1 t
+            with np.errstate(all="ignore"):                  # (2^120 times a focal length overflows: meant)
+                if what in ("cameras", "both"):
+                    a1 = (a1 * sc).astype(np.float32)       # K1^-1 p scales by 2^-k: x(2) = 2^-k
+                    a2 = (a2 / sc).astype(np.float32)
+                if what in ("translation", "both"):
+                    r[:, 30:33] = r[:, 30:33] * sc           # t' (and with it the depths, s, t and z)
+                    r[:, 18:21] = r[:, 18:21] * sc           # R^-1 t
             with np.errstate(all="ignore"):
                 want = oracle.ransac_score(r, a1, a2, p1, p2, excl)
                 got = ctx.ransac_score(r, a1, a2, p1, p2, exclude=excl, want_errors=True, want_depths=True)
