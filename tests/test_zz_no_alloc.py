@@ -98,3 +98,38 @@ def test_no_alloc_entry_point_allocates_nothing():
     finally:
         fresh.set_stream(0)
         fresh.close()
+
+
+def test_no_alloc_entry_point_under_hip_graph_capture():
+    """What the entry point is for: a caller that records its work into a HIP graph, where hipMalloc
+    (and any synchronisation) is illegal.  A two-pass scan is captured on a side stream and replayed
+    twice into a cleared output; the allocating entry point gives the expected bytes outside the graph."""
+    import torch
+    import stereo_amd
+    dev = torch.device("cuda", 0)
+    l, r = synth.rectified_pair(991, 160, 900, 300)
+    a, b = torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev)
+    out = torch.zeros((160, 900), dtype=torch.int16, device=dev)
+    want = torch.zeros((160, 900), dtype=torch.int16, device=dev)
+    fresh = stereo_amd.Context(0)
+    side = torch.cuda.Stream()
+    try:
+        fresh.set_stream(torch.cuda.current_stream().cuda_stream)
+        fresh.disparity_dev(a, b, want, win=7, max_disp=300)
+        torch.cuda.synchronize()
+        fresh.set_stream(side.cuda_stream)
+        with torch.cuda.stream(side):
+            fresh.disparity_dev_noalloc(a, b, out, win=7, max_disp=300)   # one-time kernel attributes, outside the capture
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                fresh.disparity_dev_noalloc(a, b, out, win=7, max_disp=300)
+        for _ in range(2):
+            out.zero_()
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, want)
+    finally:
+        fresh.set_stream(0)
+        fresh.close()
