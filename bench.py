@@ -709,7 +709,9 @@ def main():
             ms_cl = timed(cstep, 5)
             cst = ctx.match_stats()
             nchk = 256
-            ctx.set_match_algo(api.MATCH_EXACT)
+            # the checker: the 16-lanes-per-query exact scan, which shares nothing with the prefilter path
+            # (the one-lane-per-query kernel would take 0.4 s for any number of queries up to a full chip)
+            ctx.set_match_algo(api.MATCH_SMALL)
             try:
                 ce = [torch.empty(nchk, dtype=t_.dtype, device="cuda") for t_ in co]
                 ctx.match_dev(tc1[:nchk].contiguous(), tcs1[:nchk].contiguous(), tc2, tcs2, 1000.0, *ce)
@@ -723,7 +725,7 @@ def main():
                 "ms": ms_cl, "matched_descriptors_per_s": n / (ms_cl * 1e-3), "vs_ordinary_set": ms_cl / ms,
                 "candidates_per_query": cst["candidates_per_query"], "candidates_max": cst["candidates_max"],
                 "overflow_queries": cst["overflow_queries"],
-                "first_%d_queries_equal_exact_gpu_scan" % nchk: same_c,
+                "first_%d_queries_equal_exact_gpu_scan" % nchk: same_c,   # STX_MATCH_SMALL over all of list2
             }
     if extra and rank == 0:
         out["extra"] = extra
