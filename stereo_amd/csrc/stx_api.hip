@@ -3,6 +3,7 @@
 // launchers in disparity.hip / rectify.hip / match.hip.
 #include <mutex>
 #include <new>
+#include <stdlib.h>
 #include <string.h>
 
 #include "stx_internal.h"
@@ -210,14 +211,23 @@ extern "C" int stx_match_dev(stx_ctx *ctx, const float *d_desc1, const float *d_
                             d_closest, d_second, d_min_dist, d_second_dist, d_status);
 }
 
-// Large host-pointer matching calls run list1 in query chunks (queries are independent): chunk
-// c + 1 is staged and uploaded while chunk c is matched, so of the two uploads only list2's stays
-// in front of the compute.  (Each chunk repeats list2's preparation, ~0.1 ms at 200k rows.)
-static int match_query_chunk(int n1, int n2)
+// Large host-pointer matching calls run list1 in TWO query chunks (queries are independent): the
+// second chunk is staged and uploaded while the first is matched, so of the two uploads only list2's
+// and the first chunk's stay in front of the compute.  The first chunk is a quarter of the queries:
+// its matching (~2.3 ms at 200k x 200k) then just covers the upload of the other three quarters
+// (~2.1 ms through the staging copies), and two launches cost 0.6 ms of kernel time over one where
+// round 2's four equal chunks cost 1.3 ms (every chunk cuts the query blocks into more pieces and
+// repeats list2's preparation).  STX_MATCH_CHUNKS=1 turns the chunking off, =4 gives round 2's.
+static int match_first_chunk(int n1, int n2, int *rest_chunk)
 {
+    *rest_chunk = n1;
     if ((double)n1 * (double)n2 < 4.0e9 || n1 < 4 * 16384) return n1;
+    const char *env = getenv("STX_MATCH_CHUNKS");
+    const int mode = env ? atoi(env) : 2;
+    if (mode == 1) return n1;
     int chunk = (n1 + 3) / 4;
     chunk = (chunk + 511) / 512 * 512;  // whole query blocks of the x1 kernel
+    *rest_chunk = mode == 4 ? chunk : n1;
     return chunk;
 }
 
@@ -288,8 +298,9 @@ extern "C" int stx_match(stx_ctx *ctx, const float *desc1, const float *score1, 
     int rc = stx_host_upload_flat(ctx, dd2, desc2, d2b, d1b);
     if (!rc) rc = stx_host_upload_flat(ctx, ds2, score2, s2b, d1b + d2b + s1b);
     if (!rc) rc = stx_host_upload_flat(ctx, ds1, score1, s1b, d1b + d2b);
-    const int qc = match_query_chunk(n1, n2);
-    for (int q0 = 0; q0 < n1 && !rc; q0 += qc) {
+    int rest;
+    int qc = match_first_chunk(n1, n2, &rest);
+    for (int q0 = 0; q0 < n1 && !rc; q0 += qc, qc = rest) {
         const int q = n1 - q0 < qc ? n1 - q0 : qc;
         const size_t off = (size_t)q0 * STX_DESC_LEN;
         rc = stx_host_upload_flat(ctx, dd1 + off, desc1 + off, sizeof(float) * (size_t)q * STX_DESC_LEN,
@@ -342,8 +353,9 @@ extern "C" int stx_match_features(stx_ctx *ctx, const void *feat1, int n1, const
     }
     int rc = stx_host_upload_flat(ctx, drec + r1b, feat2, r2b, r1b);
     if (!rc) rc = stx_launch_unpack_features(ctx, drec + r1b, n2, feature_stride, desc_offset, score_offset, dd2, ds2);
-    const int qc = match_query_chunk(n1, n2);
-    for (int q0 = 0; q0 < n1 && !rc; q0 += qc) {  // list1 in query chunks: upload c + 1 behind match c
+    int rest;
+    int qc = match_first_chunk(n1, n2, &rest);
+    for (int q0 = 0; q0 < n1 && !rc; q0 += qc, qc = rest) {  // list1 in query chunks: upload c + 1 behind match c
         const int q = n1 - q0 < qc ? n1 - q0 : qc;
         const size_t roff = (size_t)q0 * feature_stride;
         rc = stx_host_upload_flat(ctx, drec + roff, (const unsigned char *)feat1 + roff, (size_t)q * feature_stride, roff);

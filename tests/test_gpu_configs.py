@@ -349,9 +349,10 @@ def test_match_on_feature_records(ctx, oracle):
         ctx.match_features(r1, r1, 40, 12)      # descriptor would leave the record
 
 
-def test_large_host_matching_runs_in_query_chunks(ctx, oracle):
-    """A host-pointer matching call this large runs list1 in four query chunks (upload of chunk
-    c + 1 behind the matching of chunk c): same outputs as the one-launch device call, for the
+def test_large_host_matching_runs_in_query_chunks(ctx, oracle, monkeypatch):
+    """A host-pointer matching call this large runs list1 in two query chunks, a quarter and three
+    quarters (the second uploads behind the matching of the first; STX_MATCH_CHUNKS=4 gives round 2's
+    four equal ones, =1 none): same outputs as the one-launch device call whichever way, for the
     separate-array and the feature-record entry points; the oracle on a sample."""
     import torch
     n1, n2 = 66_100, 61_000          # n1 * n2 > 4e9 and n1 >= 65536: chunked; ragged last chunk
@@ -368,12 +369,17 @@ def test_large_host_matching_runs_in_query_chunks(ctx, oracle):
     finally:
         ctx.set_stream(0)
     want = [o.cpu().numpy() for o in outs]
-    _match_equal(ctx.match(d1, s1, d2, s2, 1000.0), want)
     feature = np.dtype([("scale", np.int32), ("p", np.float32, 2), ("score", np.float32), ("angle", np.float32),
                         ("desc", np.float32, 128), ("distFromBestMatch", np.float32), ("depth", np.float32)])
     r1, r2 = np.zeros(n1, feature), np.zeros(n2, feature)
     r1["desc"], r1["score"], r2["desc"], r2["score"] = d1, s1, d2, s2
-    _match_equal(ctx.match_features(r1, r2, 20, 12, 1000.0), want)
+    for mode in (None, "4", "1"):
+        if mode is None:
+            monkeypatch.delenv("STX_MATCH_CHUNKS", raising=False)
+        else:
+            monkeypatch.setenv("STX_MATCH_CHUNKS", mode)
+        _match_equal(ctx.match(d1, s1, d2, s2, 1000.0), want)
+        _match_equal(ctx.match_features(r1, r2, 20, 12, 1000.0), want)
     idx = np.arange(0, n1, n1 // 40)[:40]
     _match_equal([w_[idx] for w_ in want], oracle.match(d1[idx], s1[idx], d2, s2, 1000.0))
 
