@@ -45,6 +45,59 @@ __device__ __forceinline__ uint8_t match_status(int closest, int second, float m
     return ratio < 0.8f ? STX_MATCH_ACCEPTED : STX_MATCH_RATIO;
 }
 
+// ---- rows of list2 through the scalar data path, double buffered ------------------------
+// Every lane of a wave needs the same row, so a row arrives as eight s_load_dwordx16 and its
+// elements are scalar operands of the lanes' vector instructions.  Scalar loads return out of order:
+// the only wait is lgkmcnt(0), and the compiler placed each load right in front of its wait --
+// every 64-byte chunk's full latency exposed, eight times per row (42 % vector utilisation in the
+// overflow pass, PMC).  Here the NEXT chunk is requested as soon as the current one has arrived
+// and travels while the current one is consumed (32 vector instructions); the chunk behind a
+// row's last one is the next row's first.  (Loads only: nothing is ever written through the
+// scalar cache.)
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16s row_chunk_request(const float *p)
+{
+    f32x16s v;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p));
+    return v;
+}
+
+// the chunk requested last has arrived after this (ties the wait to the value the consumer reads)
+__device__ __forceinline__ void row_chunk_arrived(f32x16s &v)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v));
+}
+
+// Squared distance of the query (64 packed pairs in registers) to the row whose first chunk has been
+// requested into `cur`; `next_row` is where the following request goes once this row's chunks are
+// through (the next row, or any valid row behind the last one).  Reference operation order:
+// differences and squares as packed fp32 (each half rounded as the scalar instruction rounds it), the
+// sum ONE accumulator in ascending k.
+__device__ __forceinline__ float row_norm2(const f32x2 (&a)[K / 2], const float *row, const float *next_row,
+                                           f32x16s &cur)
+{
+    float norm = 0.0f;
+#pragma unroll
+    for (int c = 0; c < K / 16; ++c) {
+        row_chunk_arrived(cur);
+        f32x16s now = cur;
+        // (`now` passes through the request so that its consumers cannot be scheduled in front of it)
+        asm volatile("s_load_dwordx16 %0, %2, 0x0"
+                     : "=&s"(cur), "+s"(now)
+                     : "s"(c + 1 < K / 16 ? row + 16 * (c + 1) : next_row));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x2 b = {now[2 * k], now[2 * k + 1]};
+            const f32x2 d = a[8 * c + k] - b;
+            const f32x2 sq = d * d;
+            norm = norm + sq.x;
+            norm = norm + sq.y;
+        }
+    }
+    return norm;
+}
+
 // ---------------------------------------------------------------------------
 // Exact scan: one lane per query, the query's 128 floats in registers, list2
 // rows streamed through the scalar data path (every lane reads the same row).
@@ -85,16 +138,11 @@ __global__ __launch_bounds__(EXACT_THREADS) void match_exact_kernel(
     int closest = -1, second = -1;
     float min_dist = -1.0f;  // Features.cpp:1035
     float min_norm2 = 0.0f;
+    f32x16s chunk = {};
+    if (n2 > 0) chunk = row_chunk_request(desc2);  // (n2 == 0: nothing to read, desc2 may be null)
     for (int j = 0; j < n2; ++j) {
-        const f32x2 *__restrict__ b = reinterpret_cast<const f32x2 *>(desc2 + (size_t)j * K);
-        float norm = 0.0f;
-#pragma unroll
-        for (int k = 0; k < K / 2; ++k) {
-            const f32x2 d = a[k] - b[k];
-            const f32x2 sq = d * d;
-            norm = norm + sq.x;
-            norm = norm + sq.y;
-        }
+        const float *row = desc2 + (size_t)j * K;
+        const float norm = row_norm2(a, row, j + 1 < n2 ? row + K : row, chunk);
         if (j == 0) {  // minDist == -1 branch of :1041
             closest = 0;
             min_norm2 = norm;
@@ -109,6 +157,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void match_exact_kernel(
             }
         }
     }
+    if (n2 > 0) row_chunk_arrived(chunk);  // the request behind the last row: nothing in flight at the end
     if (!active) return;
 
     float second_dist = -1.0f;
@@ -143,7 +192,8 @@ __global__ __launch_bounds__(EXACT_THREADS) void match_exact_kernel(
 // segment has no record yet: a row at +inf or NaN is never a record there, and never one of the full
 // scan either (nothing is < a minimum that row 0 has already set).
 // ---------------------------------------------------------------------------
-constexpr int OVF_WAVES = 4096;      // waves per launch (4 per SIMD on 256 CUs)
+constexpr int OVF_WAVES = 3072;      // waves per launch: 3 per SIMD on 256 CUs -- the kernel holds the query in 128 VGPRs
+                                     // (165 in all), so three waves share a SIMD and a fourth would wait for a second round
 constexpr int OVF_MAX_SEGS = 2048;   // segments per query group at most
 
 struct OvfPartial {
@@ -200,16 +250,10 @@ __global__ __launch_bounds__(64) void match_exact_seg_kernel(
         int closest = -1, second = -1;
         float min_dist = __builtin_inff(), second_dist = -1.0f;
         float min_norm2 = __builtin_inff();
+        f32x16s chunk = row_chunk_request(desc2 + (size_t)j_begin * K);
         for (int j = j_begin; j < j_end; ++j) {
-            const f32x2 *__restrict__ b = reinterpret_cast<const f32x2 *>(desc2 + (size_t)j * K);
-            float norm = 0.0f;
-#pragma unroll
-            for (int k = 0; k < K / 2; ++k) {
-                const f32x2 d = a[k] - b[k];
-                const f32x2 sq = d * d;
-                norm = norm + sq.x;
-                norm = norm + sq.y;
-            }
+            const float *row = desc2 + (size_t)j * K;
+            const float norm = row_norm2(a, row, j + 1 < j_end ? row + K : row, chunk);
             if (j == 0) {  // minDist == -1 branch of :1041: taken whatever the value
                 closest = 0;
                 min_norm2 = norm;
@@ -225,6 +269,7 @@ __global__ __launch_bounds__(64) void match_exact_seg_kernel(
                 }
             }
         }
+        row_chunk_arrived(chunk);  // the request behind the segment's last row
         if (active) {
             OvfPartial r;
             r.closest = closest;
