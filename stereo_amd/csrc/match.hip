@@ -1119,7 +1119,7 @@ __device__ __forceinline__ void x1_block(const uint4 (&f)[8], const bf16x8 (&qh0
 __global__ __launch_bounds__(X1_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
     const float *__restrict__ desc1, const float *__restrict__ qnorm, int n1,
     const uint4 *__restrict__ frag16, const float *__restrict__ bmax, int n2,
-    int tiles_total, long long per, long long flat_total, int nsub, int subcap,
+    int tiles_total, long long per, long long flat_total, int grid_segs, int nsub, int subcap,
     int *__restrict__ cand_count, int *__restrict__ cand, const float *__restrict__ ywarm)
 {
     // Two separate LDS objects, not one [2][..] array: the tile staging is an LDS DMA
@@ -1165,7 +1165,25 @@ __global__ __launch_bounds__(X1_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
     auto staged = [&]() __attribute__((always_inline)) { __builtin_amdgcn_s_waitcnt(0x0F70); };
 
     long long flat = (long long)blockIdx.x * per;
-    const long long flat_end = flat + per < flat_total ? flat + per : flat_total;
+    long long flat_end = flat + per < flat_total ? flat + per : flat_total;
+    int grid_piece = -1;
+    if (grid_segs > 0) {
+        // Few query blocks (list1 sharded over GPUs): a (segment of list2, query block) grid instead of
+        // the flat cut.  Workgroups b, b + 8, b + 16, ... share an XCD and its L2; numbered XCD by XCD,
+        // neighbours take the SAME segment for consecutive query blocks, so an XCD's 32 workgroups
+        // stream one stretch of list2 in step and all but the first reader of a tile hit in L2 -- where
+        // the flat cut has them at 32 different positions of list2 (14 % slower per tile, measured).
+        const int per_xcd = (int)gridDim.x / 8;
+        const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+        const int qblocks = (int)(flat_total / tiles_total);
+        if (logical >= qblocks * grid_segs) return;
+        grid_piece = logical / qblocks;
+        const int qb = logical - grid_piece * qblocks;
+        flat = (long long)qb * tiles_total + (long long)grid_piece * per;
+        flat_end = flat + per;
+        const long long row_end = (long long)(qb + 1) * tiles_total;
+        flat_end = flat_end < row_end ? flat_end : row_end;
+    }
 #pragma unroll 1
     while (flat < flat_end) {
         const int qb = (int)(flat / tiles_total);
@@ -1175,7 +1193,7 @@ __global__ __launch_bounds__(X1_WAVES * 64, 2) void match_mfma_bf16x1_kernel(
         const int ntiles = t_end - t_begin;
         flat += ntiles;
         // pieces of a query block are numbered from the first workgroup that touches it
-        const int piece = (int)blockIdx.x - (int)(((long long)qb * tiles_total) / per);
+        const int piece = grid_piece >= 0 ? grid_piece : (int)blockIdx.x - (int)(((long long)qb * tiles_total) / per);
 
         const int q0i = qb * X1_QB + wave * MF_QW + col;
         const int q1i = q0i + 32;
@@ -1715,8 +1733,19 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
         const long long wgs_aligned = (flat_total + per_aligned - 1) / per_aligned;
         if (wgs_aligned * 100 >= (long long)slots * 96) per = per_aligned;
     }
-    const int x1_wgs = (int)((flat_total + per - 1) / per);
-    const int max_pieces = (int)((tiles_total + per - 1) / per) + 1;
+    int x1_wgs = (int)((flat_total + per - 1) / per);
+    int max_pieces = (int)((tiles_total + per - 1) / per) + 1;
+    // few query blocks: the (segment, query block) grid of the kernel's comment, when it fills the chip
+    int grid_segs = 0;
+    if (x1 && slots % 8 == 0 && qblocks * 2 <= slots && tiles_total >= 256) {
+        const int S = slots / qblocks;
+        if ((long long)qblocks * S * 100 >= (long long)slots * 94 && getenv("STX_MATCH_FLAT_CUT") == nullptr) {
+            grid_segs = S;
+            per = (tiles_total + S - 1) / S;
+            x1_wgs = slots;
+            max_pieces = S;
+        }
+    }
     // candidate lists: one list of MF_CAP slots per query filled with atomics (fp32 / bf16x3
     // kernels), or two private sub-lists per piece (x1 kernel)
     const int nsub = x1 ? 2 * max_pieces + 1 : 1;  // x1: + the warm kernel's list
@@ -1760,7 +1789,7 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
                            bnorm, reinterpret_cast<const float *>(bmax), ywarm, nsub, subcap, cnt, cand, ovf_count);
         hipLaunchKernelGGL(match_mfma_bf16x1_kernel, dim3(x1_wgs), dim3(X1_WAVES * 64), 0, st, d_desc1, qnorm,
                            n1, reinterpret_cast<const uint4 *>(frag), reinterpret_cast<const float *>(bmax), n2,
-                           tiles_total, per, flat_total, nsub, subcap, cnt, cand, ywarm);
+                           tiles_total, per, flat_total, grid_segs, nsub, subcap, cnt, cand, ywarm);
     }
     else if (bf16)
         hipLaunchKernelGGL(match_mfma_bf16_kernel, dim3(qblocks, segs), dim3(MF_WAVES * 64), 0, st, d_desc1, qnorm,
