@@ -1731,7 +1731,7 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
         const long long u = tiles_total / 32;
         const long long per_aligned = (per + u - 1) / u * u;
         const long long wgs_aligned = (flat_total + per_aligned - 1) / per_aligned;
-        if (wgs_aligned * 100 >= (long long)slots * 96) per = per_aligned;
+        if (wgs_aligned * 100 >= (long long)slots * 94) per = per_aligned;
     }
     int x1_wgs = (int)((flat_total + per - 1) / per);
     int max_pieces = (int)((tiles_total + per - 1) / per) + 1;
