@@ -89,6 +89,63 @@ __global__ __launch_bounds__(WAVES * 64) void k(const uint4 *in, float *out, int
     if (s == 123.456f) out[0] = s;
 }
 
+// three chains per wave (a wave that owns three query groups): 24 MFMAs per iteration, NV v_max3, NL reads
+template <int NV, int NL, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k3(const uint4 *in, float *out, int iters)
+{
+    __shared__ uint4 lds[2048];
+    for (int i = threadIdx.x; i < 2048; i += WAVES * 64) lds[i] = in[i & 511];
+    __syncthreads();
+    uint4 ua = in[threadIdx.x & 255], ub = in[(threadIdx.x & 255) + 256];
+    bf16x8 a = __builtin_bit_cast(bf16x8, ua), b = __builtin_bit_cast(bf16x8, ub);
+    f32x16 x0 = 0, x1 = 0, x2 = 0;
+    float m0 = 0.f, m1 = 1.f, m2 = 2.f, m3 = 3.f, m4 = 4.f;
+    uint4 acc4 = make_uint4(0, 0, 0, 0);
+    const uint4 *lp = lds + (threadIdx.x & 63);
+    for (int i = 0; i < iters; ++i) {
+        uint4 f[NL > 0 ? NL : 1];
+        const unsigned addr = (unsigned)(size_t)lp + (i & 1) * 16384;
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[l]) : "v"(addr), "n"((l & 15) * 1024));
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, x0, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < NV / 24; ++v) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m0) : "v"(m2), "v"(m3));
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, x1, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < NV / 24; ++v) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m1) : "v"(m2), "v"(m3));
+            x2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, x2, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < NV / 24; ++v) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m4) : "v"(m2), "v"(m3));
+        }
+        if (NL > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int l = 0; l < NL; ++l) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(acc4.x) : "v"(f[l].x));
+    }
+    float s = m0 + m1 + m4 + (float)acc4.x + (float)acc4.y;
+    for (int r = 0; r < 16; ++r) s += x0[r] + x1[r] + x2[r];
+    if (s == 123.456f) out[0] = s;
+}
+
+template <int NV, int NL, int WAVES> static void run3(const uint4 *in, float *out, int cus)
+{
+    const int iters = 14000;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k3<NV, NL, WAVES>), dim3(cus), dim3(WAVES * 64), 0, 0, in, out, iters / 2);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k3<NV, NL, WAVES>), dim3(cus), dim3(WAVES * 64), 0, 0, in, out, iters);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double flop = 2.0 * 32 * 32 * 16 * 24 * (double)iters * cus * WAVES;
+    printf("THREE chains: waves/SIMD %d  v_max3 %3d  ds_read_b128 %2d per 24 MFMAs: %7.3f ms  %6.0f TFLOP/s\n", WAVES / 4, NV, NL, ms,
+           flop / (ms * 1e-3) / 1e12);
+}
+
 template <int NV, int NL, int WAVES> static void run_spread(const uint4 *in, float *out, int cus)
 {
     const int iters = 20000;
@@ -139,5 +196,8 @@ int main()
     run_spread<0, 4, 8>(in, out, cus); run_spread<0, 8, 8>(in, out, cus); run_spread<0, 12, 8>(in, out, cus); run_spread<48, 12, 8>(in, out, cus); run_spread<0, 16, 8>(in, out, cus);
     run_spread<0, 12, 4>(in, out, cus); run_spread<48, 12, 4>(in, out, cus);
     run<0, 0, 16>(in, out, cus, 0); run<48, 12, 16>(in, out, cus, 0);
+    // round 3: would a wave with three query groups (12 reads per 24 MFMAs, the same vector work per MFMA) do better?
+    run<48, 12, 8>(in, out, cus, 0); run3<72, 12, 8>(in, out, cus); run3<48, 12, 8>(in, out, cus); run3<96, 12, 8>(in, out, cus);
+    run3<72, 0, 8>(in, out, cus); run3<0, 0, 8>(in, out, cus); run<64, 12, 8>(in, out, cus, 0); run3<96, 18, 8>(in, out, cus);
     return 0;
 }
