@@ -110,6 +110,11 @@ int stx_match_stats(stx_ctx *ctx, long long *total_candidates, int *max_candidat
  * between passes, matching work lists ...).  Diagnostic; no counterpart in the reference. */
 size_t stx_workspace_bytes(const stx_ctx *ctx);
 
+/* Page-locked host bytes the context currently holds as staging for the host-pointer entry points
+ * (0 when every buffer it was given was already page-locked, or when the host had none to give and
+ * the calls went on with plain copies).  Diagnostic; no counterpart in the reference. */
+size_t stx_staging_bytes(const stx_ctx *ctx);
+
 /* How the host-pointer entry points would treat the caller's buffer [p, p + bytes):
  *   0  pageable (or not inside ONE page-locked allocation the HIP runtime knows): staged through the
  *      library's pinned buffers;

@@ -45,6 +45,7 @@ PROTOTYPES = {
     "stx_synchronize": (C.c_int, [_vp]),
     "stx_set_match_algo": (C.c_int, [_vp, C.c_int]),
     "stx_workspace_bytes": (C.c_size_t, [_vp]),
+    "stx_staging_bytes": (C.c_size_t, [_vp]),
     "stx_host_buffer_kind": (C.c_int, [_vp, _vp, C.c_size_t]),
     "stx_match_stats": (C.c_int, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(C.c_int)]),

@@ -96,6 +96,10 @@ class Context:
         """Device bytes held in the context's grow-only workspace slots."""
         return int(self._lib.stx_workspace_bytes(self._h))
 
+    def staging_bytes(self):
+        """Page-locked host bytes held as staging for the host-pointer calls."""
+        return int(self._lib.stx_staging_bytes(self._h))
+
     def host_buffer_kind(self, arr):
         """0 pageable / 1 page-locked (DMA direct) / 2 page-locked and kernel-visible, for a numpy array's memory."""
         a = np.asarray(arr)

@@ -111,6 +111,8 @@ extern "C" size_t stx_workspace_bytes(const stx_ctx *ctx)
     return total;
 }
 
+extern "C" size_t stx_staging_bytes(const stx_ctx *ctx) { return ctx ? ctx->pin_bytes[0] + ctx->pin_bytes[1] : 0; }
+
 extern "C" int stx_host_buffer_kind(stx_ctx *ctx, const void *p, size_t bytes)
 {
     if (!ctx) return STX_ERR_INVALID_ARG;
@@ -235,6 +237,26 @@ static int match_first_chunk(int n1, int n2, int *rest_chunk)
 // they come back in ONE copy into pinned memory and are split on the host: for a few hundred
 // features (BASELINE config 1) five pageable copies of a few hundred bytes each cost more than
 // the matching itself.  Larger results go straight to the caller's arrays.
+// Page-locked staging for one call, or none: when the host has no page-locked memory left to give,
+// the call goes on with plain copies of the caller's buffers (host_pipeline == 0 for its duration).
+struct StagingScope {
+    stx_ctx *ctx;
+    int saved;
+    explicit StagingScope(stx_ctx *c) : ctx(c), saved(c->host_pipeline) {}
+    ~StagingScope() { ctx->host_pipeline = saved; }
+    int prepare(size_t in_bytes, size_t out_bytes)
+    {
+        if (!stx_host_pipeline_on(ctx)) return STX_OK;
+        const int rc = stx_host_prepare(ctx, in_bytes, out_bytes);
+        if (rc == (int)hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            ctx->host_pipeline = 0;
+            return STX_OK;
+        }
+        return rc ? rc : stx_host_fence(ctx);
+    }
+};
+
 static int match_download(stx_ctx *ctx, int n1, size_t n1a, const int32_t *dcl, int32_t *closest, int32_t *second,
                           float *min_dist, float *second_dist, uint8_t *status)
 {
@@ -288,16 +310,16 @@ extern "C" int stx_match(stx_ctx *ctx, const float *desc1, const float *score1, 
     uint8_t *dst = (uint8_t *)(dsd + n1a);
     // the two descriptor lists (config 5: 102 MB each) go through the staging pipeline
     const size_t s1b = 4 * (size_t)n1, s2b = 4 * (size_t)n2;
-    if (stx_host_pipeline_on(ctx)) {
-        int prc = stx_host_prepare(ctx, d1b + d2b + s1b + s2b, n1 <= 65536 ? 17 * n1a : 0);
-        if (prc) return prc;
-        prc = stx_host_fence(ctx);
-        if (prc) return prc;
-    }
+    // staging only for the arrays that need it: a page-locked list is DMA'd as it lies (the
+    // call used to pin room for both lists -- 256 MB at config 5 -- whether they were staged or not)
+    const size_t st1 = stx_host_is_pinned(desc1, d1b) ? 0 : d1b, st2 = stx_host_is_pinned(desc2, d2b) ? 0 : d2b;
+    StagingScope staging(ctx);
+    const int prc = staging.prepare(st1 + st2 + s1b + s2b, n1 <= 65536 ? 17 * n1a : 0);
+    if (prc) return prc;
     // list2 first (its preparation depends on nothing in list1), then list1 in query chunks
-    int rc = stx_host_upload_flat(ctx, dd2, desc2, d2b, d1b);
-    if (!rc) rc = stx_host_upload_flat(ctx, ds2, score2, s2b, d1b + d2b + s1b);
-    if (!rc) rc = stx_host_upload_flat(ctx, ds1, score1, s1b, d1b + d2b);
+    int rc = stx_host_upload_flat(ctx, dd2, desc2, d2b, st1);
+    if (!rc) rc = stx_host_upload_flat(ctx, ds2, score2, s2b, st1 + st2 + s1b);
+    if (!rc) rc = stx_host_upload_flat(ctx, ds1, score1, s1b, st1 + st2);
     int rest;
     int qc = match_first_chunk(n1, n2, &rest);
     for (int q0 = 0; q0 < n1 && !rc; q0 += qc, qc = rest) {
@@ -345,13 +367,11 @@ extern "C" int stx_match_features(stx_ctx *ctx, const void *feat1, int n1, const
     float *dsd = dmd + n1a;
     uint8_t *dst = (uint8_t *)(dsd + n1a);
     // list2 first: its preparation (norms, fragments) depends on nothing in list1
-    if (stx_host_pipeline_on(ctx)) {
-        int prc = stx_host_prepare(ctx, r1b + r2b, n1 <= 65536 ? 17 * n1a : 0);
-        if (prc) return prc;
-        prc = stx_host_fence(ctx);
-        if (prc) return prc;
-    }
-    int rc = stx_host_upload_flat(ctx, drec + r1b, feat2, r2b, r1b);
+    const size_t st1 = stx_host_is_pinned(feat1, r1b) ? 0 : r1b, st2 = stx_host_is_pinned(feat2, r2b) ? 0 : r2b;
+    StagingScope staging(ctx);
+    const int prc = staging.prepare(st1 + st2, n1 <= 65536 ? 17 * n1a : 0);
+    if (prc) return prc;
+    int rc = stx_host_upload_flat(ctx, drec + r1b, feat2, r2b, st1);
     if (!rc) rc = stx_launch_unpack_features(ctx, drec + r1b, n2, feature_stride, desc_offset, score_offset, dd2, ds2);
     int rest;
     int qc = match_first_chunk(n1, n2, &rest);
@@ -662,13 +682,12 @@ extern "C" int stx_rectify_disparity_u8(stx_ctx *ctx, const uint8_t *img0, const
     if (!drect) return err;
     uint8_t *dout = (uint8_t *)stx_workspace(ctx, STX_SLOT_OUT, img, &err);
     if (!dout) return err;
-    const bool pipe = stx_host_pipeline_on(ctx);
     const int nout = 1 + (rect0 ? 1 : 0) + (rect1 ? 1 : 0);
+    StagingScope staging(ctx);
+    rc = staging.prepare(2 * img, (size_t)nout * img);
+    if (rc) return rc;
+    const bool pipe = stx_host_pipeline_on(ctx);
     if (pipe) {
-        rc = stx_host_prepare(ctx, 2 * img, (size_t)nout * img);
-        if (rc) return rc;
-        rc = stx_host_fence(ctx);
-        if (rc) return rc;
         uint8_t *pin_in = (uint8_t *)ctx->pin_ptr[0];
         // row chunks: the staging copy of chunk c+1 runs while chunk c is on the bus
         const int nc = stx_host_chunks(ctx, img, (size_t)h);

@@ -243,6 +243,11 @@ int stx_host_prepare(stx_ctx *ctx, size_t in_bytes, size_t out_bytes)
         ctx->pin_ptr[i] = nullptr;
         ctx->pin_bytes[i] = 0;
         const size_t bytes = (want[i] + (want[i] >> 2) + 65535) & ~(size_t)65535;  // 25 % headroom
+        // STX_PIN_LIMIT_MB caps what one staging buffer may page-lock (hosts with a small memlock
+        // allowance): a request above it is answered as an exhausted host would answer it, and the
+        // callers go on with plain copies
+        const char *cap = getenv("STX_PIN_LIMIT_MB");
+        if (cap && *cap && bytes > ((size_t)strtoull(cap, nullptr, 10) << 20)) return (int)hipErrorOutOfMemory;
         void *p = nullptr;
         STX_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
         ctx->pin_ptr[i] = p;
@@ -752,27 +757,49 @@ static int drain_on_error(stx_ctx *ctx, int rc)
     return rc;
 }
 
+// Pinned staging is a convenience, not a requirement: if a pipeline ran out of (page-locked host)
+// memory, the call is repeated once with plain copies of the caller's buffers, which need none.
+template <class F>
+static int with_plain_copy_fallback(stx_ctx *ctx, F call)
+{
+    int rc = call();
+    if (rc == (int)hipErrorOutOfMemory && stx_host_pipeline_on(ctx)) {
+        (void)hipGetLastError();
+        const int saved = ctx->host_pipeline;
+        ctx->host_pipeline = 0;
+        rc = call();
+        ctx->host_pipeline = saved;
+    }
+    return rc;
+}
+
 int stx_disparity_host(stx_ctx *ctx, const uint8_t *img0, const uint8_t *img1, int n_pairs, int w, int h,
                        size_t stride, size_t pair_stride, int row0, int rows, int win, int max_disp,
                        int cost_mode, void *out, size_t out_stride, size_t out_pair_stride, int out_bytes)
 {
-    return drain_on_error(ctx, disparity_host_pipeline(ctx, img0, img1, n_pairs, w, h, stride, pair_stride, row0, rows,
-                                                       win, max_disp, cost_mode, out, out_stride, out_pair_stride,
-                                                       out_bytes));
+    return with_plain_copy_fallback(ctx, [&] {
+        return drain_on_error(ctx, disparity_host_pipeline(ctx, img0, img1, n_pairs, w, h, stride, pair_stride, row0, rows,
+                                                           win, max_disp, cost_mode, out, out_stride, out_pair_stride,
+                                                           out_bytes));
+    });
 }
 
 int stx_rectify_host(stx_ctx *ctx, const uint8_t *src, int src_w, int src_h, size_t src_stride, uint8_t *dst,
                      int dst_w, int dst_h, size_t dst_stride, const float Hinv[9], int flags, uint8_t *d_keep)
 {
-    return drain_on_error(ctx, rectify_host_pipeline(ctx, src, src_w, src_h, src_stride, dst, dst_w, dst_h, dst_stride,
-                                                     Hinv, flags, d_keep));
+    return with_plain_copy_fallback(ctx, [&] {
+        return drain_on_error(ctx, rectify_host_pipeline(ctx, src, src_w, src_h, src_stride, dst, dst_w, dst_h, dst_stride,
+                                                         Hinv, flags, d_keep));
+    });
 }
 
 int stx_disparity_resident_host(stx_ctx *ctx, const uint8_t *d_img0, const uint8_t *d_img1, int w, int h, int win,
                                 int max_disp, int cost_mode, void *out, size_t out_stride, int out_bytes)
 {
-    return drain_on_error(ctx, disparity_resident_host_pipeline(ctx, d_img0, d_img1, w, h, win, max_disp, cost_mode,
-                                                                out, out_stride, out_bytes));
+    return with_plain_copy_fallback(ctx, [&] {
+        return drain_on_error(ctx, disparity_resident_host_pipeline(ctx, d_img0, d_img1, w, h, win, max_disp, cost_mode,
+                                                                    out, out_stride, out_bytes));
+    });
 }
 
 // ------------------------------------------------------ flat arrays (M, ...) --

@@ -493,6 +493,52 @@ def test_page_locked_caller_buffers_skip_the_staging(ctx, oracle):
             ctx.set_host_pipeline(True, 0, 0)
 
 
+def test_no_page_locked_memory_falls_back_to_plain_copies(oracle, monkeypatch):
+    """pinned staging is a convenience.  With no page-locked memory to be had
+    (STX_PIN_LIMIT_MB makes the staging request fail the way an exhausted host fails it) every
+    host-pointer call goes on with plain copies and gives the same bytes; and a matching call on
+    page-locked lists asks for no staging for them at all."""
+    import stereo_amd
+    import torch
+    h, w = 300, 1100
+    l, r = synth.rectified_pair(51, h, w, 64)
+    src = synth.texture(52, h, w)
+    Hinv = oracle.invert3x3(synth.homography(5, w, h))
+    want = oracle.disparity_ext(l, r, 9, 64, 0, sliding=True)
+    wantr = oracle.rectify(src, np.zeros_like(src), Hinv)
+    n1, n2 = 3000, 2500
+    d1, s1, d2, s2 = synth.descriptor_sets(9, n1, n2)
+    wantm = oracle.match(d1, s1, d2, s2, 1000.0)
+    feature = np.dtype([("scale", np.int32), ("p", np.float32, 2), ("score", np.float32), ("angle", np.float32),
+                        ("desc", np.float32, 128), ("distFromBestMatch", np.float32), ("depth", np.float32)])
+    r1, r2 = np.zeros(n1, feature), np.zeros(n2, feature)
+    r1["desc"], r1["score"], r2["desc"], r2["score"] = d1, s1, d2, s2
+    wl, wr = oracle.rectify(l, np.zeros_like(l), Hinv), oracle.rectify(r, np.zeros_like(r), Hinv)
+    wantf = oracle.disparity_ext(wl, wr, 9, 64, 0)
+    monkeypatch.setenv("STX_PIN_LIMIT_MB", "0")
+    c = stereo_amd.Context(0)
+    try:
+        for _ in range(2):      # the second round finds the context as the first left it
+            assert (c.disparity(l, r, win=9, max_disp=64) == want).all()
+            dst = np.zeros_like(src)
+            c.rectify(src, dst, Hinv, api.RECT_DST_IS_ZERO)
+            assert (dst == wantr).all()
+            got, f0, f1 = c.rectify_disparity(l, r, Hinv, Hinv, win=9, max_disp=64, want_rectified=True)
+            assert (f0 == wl).all() and (f1 == wr).all() and (got == wantf).all()
+            _match_equal(c.match(d1, s1, d2, s2, 1000.0), wantm)
+            _match_equal(c.match_features(r1, r2, 20, 12, 1000.0), wantm)
+        assert c.staging_bytes() == 0
+        # page-locked lists: 1.5 MB each; a 1 MB allowance is enough for the scores and the results
+        monkeypatch.setenv("STX_PIN_LIMIT_MB", "1")
+        p1 = torch.from_numpy(d1).pin_memory()
+        p2 = torch.from_numpy(d2).pin_memory()
+        _match_equal(c.match(p1.numpy(), s1, p2.numpy(), s2, 1000.0), wantm)
+        got = c.staging_bytes()
+        assert 0 < got <= 2 << 20
+    finally:
+        c.close()
+
+
 def test_page_locked_ranges_and_their_kernel_addresses(ctx, oracle):
     """a caller buffer counts as page-locked only if the WHOLE range lies inside one
     allocation the runtime knows (both ends being host memory is not enough), and kernels store
