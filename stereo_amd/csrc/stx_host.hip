@@ -231,6 +231,15 @@ bool stx_host_zero_copy_on()
     return on != 0;
 }
 
+// Bytes of images and maps that one group of a batch holds on the device and in staging
+// (STX_HOST_GROUP_MB: tests cut a small batch into several groups with it).
+static size_t batch_group_bytes()
+{
+    const char *e = getenv("STX_HOST_GROUP_MB");
+    const size_t mb = e && *e ? (size_t)strtoull(e, nullptr, 10) : 0;
+    return (mb ? mb : 256) << 20;
+}
+
 // pinned staging of at least in_bytes / out_bytes, the two copy streams, events, workers
 int stx_host_prepare(stx_ctx *ctx, size_t in_bytes, size_t out_bytes)
 {
@@ -394,7 +403,7 @@ static int disparity_host_pipeline(stx_ctx *ctx, const uint8_t *img0, const uint
         hipStream_t s = ctx->stream;
         // groups of pairs that fit a modest staging area
         const size_t per_pair = 2 * img + oimg;
-        int group = (int)(((size_t)768 << 20) / (per_pair ? per_pair : 1));
+        int group = (int)(batch_group_bytes() / (per_pair ? per_pair : 1));
         group = group < 1 ? 1 : group > n_pairs ? n_pairs : group;
         uint8_t *d0 = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG0, img * group, &err);
         if (!d0) return err;
@@ -511,10 +520,18 @@ static int disparity_host_pipeline(stx_ctx *ctx, const uint8_t *img0, const uint
     }
 
     // ---- a batch: groups of pairs, each group cut into chunks of pairs -------------
+    // (256 MB of images and maps per group: 41 pairs of 1080p, 3 ms of scanning between two fences;
+    // the device workspace and the page-locked staging of every context of an stx_multi are this big)
     const size_t per_pair = 2 * img + oimg;
-    int group = (int)(((size_t)768 << 20) / (per_pair ? per_pair : 1));
+    int group = (int)(batch_group_bytes() / (per_pair ? per_pair : 1));
     group = group < 1 ? 1 : group > n_pairs ? n_pairs : group;
-    int rc = stx_host_prepare(ctx, 2 * img * group, oimg * group);
+    // page-locked, dense caller arrays (checked over the whole batch) are read / written by the DMA
+    // engines directly and need no staging: the staging copies are what bounds a pageable batch
+    const size_t span = (size_t)(n_pairs - 1) * pair_stride + img;
+    const bool in_direct = stride == p && stx_host_is_pinned(img0 + (size_t)b0 * stride, span) &&
+                           stx_host_is_pinned(img1 + (size_t)b0 * stride, span);
+    const bool out_direct = out_stride == op && out_pair_stride == oimg && stx_host_is_pinned(o, (size_t)n_pairs * oimg);
+    int rc = stx_host_prepare(ctx, in_direct ? 0 : 2 * img * group, out_direct ? 0 : oimg * group);
     if (rc) return rc;
     uint8_t *d0 = (uint8_t *)stx_workspace(ctx, STX_SLOT_IMG0, img * group, &err);
     if (!d0) return err;
@@ -523,12 +540,6 @@ static int disparity_host_pipeline(stx_ctx *ctx, const uint8_t *img0, const uint
     uint8_t *dout = (uint8_t *)stx_workspace(ctx, STX_SLOT_OUT, oimg * group, &err);
     if (!dout) return err;
     uint8_t *pin_in = (uint8_t *)ctx->pin_ptr[0], *pin_out = (uint8_t *)ctx->pin_ptr[1];
-    // page-locked, dense caller arrays (checked over the whole batch) are read / written by the DMA
-    // engines directly: the staging copies are what bounds a pageable batch
-    const size_t span = (size_t)(n_pairs - 1) * pair_stride + img;
-    const bool in_direct = stride == p && stx_host_is_pinned(img0 + (size_t)b0 * stride, span) &&
-                           stx_host_is_pinned(img1 + (size_t)b0 * stride, span);
-    const bool out_direct = out_stride == op && out_pair_stride == oimg && stx_host_is_pinned(o, (size_t)n_pairs * oimg);
     for (int g0 = 0; g0 < n_pairs; g0 += group) {
         const int g = n_pairs - g0 < group ? n_pairs - g0 : group;
         const int nc = stx_host_chunks(ctx, per_pair * g, (size_t)g);

@@ -493,6 +493,33 @@ def test_page_locked_caller_buffers_skip_the_staging(ctx, oracle):
             ctx.set_host_pipeline(True, 0, 0)
 
 
+def test_batch_larger_than_one_group(oracle, monkeypatch):
+    """A batch that does not fit one group of the host path (256 MB of images and maps; here
+    STX_HOST_GROUP_MB=5 holds two 500 x 1400 pairs) runs group after group, the last one ragged:
+    same maps as pair-by-pair calls, pageable and page-locked, with and without the pipeline."""
+    import stereo_amd
+    import torch
+    from stereo_amd import MultiContext
+    h, w, n = 500, 1400, 5
+    pairs = [synth.rectified_pair(60 + k, h, w, 64) for k in range(n)]
+    bl, br = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+    want = np.stack([oracle.disparity_ext(bl[k], br[k], 9, 64, 0, sliding=True) for k in range(n)])
+    pl, pr, po = (torch.empty((n, h, w), dtype=torch.uint8, pin_memory=True) for _ in range(3))
+    pl.numpy()[...] = bl
+    pr.numpy()[...] = br
+    monkeypatch.setenv("STX_HOST_GROUP_MB", "5")
+    for pipeline in ("1", "0"):
+        monkeypatch.setenv("STX_HOST_PIPELINE", pipeline)
+        mc = MultiContext([0])
+        try:
+            assert (mc.disparity_batch(bl, br, win=9, max_disp=64) == want).all()
+            po.numpy()[...] = 7
+            assert (mc.disparity_batch(pl.numpy(), pr.numpy(), win=9, max_disp=64, out=po.numpy()) == want).all()
+            assert (mc.disparity_batch(pl.numpy(), br, win=9, max_disp=64) == want).all()
+        finally:
+            mc.close()
+
+
 def test_no_page_locked_memory_falls_back_to_plain_copies(oracle, monkeypatch):
     """pinned staging is a convenience.  With no page-locked memory to be had
     (STX_PIN_LIMIT_MB makes the staging request fail the way an exhausted host fails it) every
