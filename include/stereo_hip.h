@@ -380,6 +380,14 @@ int stx_ransac_score_dev(stx_ctx *ctx, const float *hyp, int n_hyp, const float 
                          float threshold, int32_t *d_inliers, float *d_err_sum, float *d_errors,
                          float *d_depths);
 
+/* The second half of that loop on its own (stereo/Stereography.cpp:232-236): for each of n_hyp rows
+ * of n per-pair errors, inliers[h] = the number of errors e with 0 <= e < threshold and err_sum[h] =
+ * their fp32 sum taken in pair order, avgError += reprojectionError, bit for bit (negative and NaN
+ * entries -- the -1 of excluded pairs -- are skipped).  stx_ransac_score* end with this step; callers
+ * that compute the errors themselves can use it alone.  Device pointers; asynchronous. */
+int stx_inlier_sum_dev(stx_ctx *ctx, const float *d_errors, int n_hyp, int n, float threshold,
+                       int32_t *d_inliers, float *d_err_sum);
+
 /* ---- R+D fused on the device ---------------------------------------------
  * main.cpp:362-380 in one call: both images are rectified into zero-initialised
  * destinations of the source size (RectifyImage twice, Stereography.cpp:596-631) and the

@@ -106,6 +106,7 @@ PROTOTYPES = {
     "stx_sift_descriptors_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_int, _vp, _vp]),
     "stx_ransac_score": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_float, _vp, _vp, _vp,
                                    _vp]),
+    "stx_inlier_sum_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp]),
     "stx_ransac_score_dev": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_float, _vp, _vp,
                                        _vp, _vp]),
     "stx_gaussian_kernel": (C.c_int, [C.c_int, C.c_float, _f32p]),

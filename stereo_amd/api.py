@@ -430,6 +430,16 @@ class Context:
                                              depths.data_ptr() if depths is not None else None),
               "stx_ransac_score_dev")
 
+    def inlier_sum_dev(self, errors, threshold, inliers, err_sum):
+        """Stereography.cpp:232-236 over rows of given errors.  Device tensors: errors [H,n] float32,
+        inliers [H] int32, err_sum [H] float32."""
+        nh, n = int(errors.shape[0]), int(errors.shape[1])
+        for t, shape, name in ((errors, (nh, n), "errors"), (inliers, (nh,), "inliers"), (err_sum, (nh,), "err_sum")):
+            if tuple(t.shape) != shape or not t.is_contiguous() or t.element_size() != 4:
+                raise ValueError("%s must be a contiguous 4-byte tensor of shape %s" % (name, shape))
+        check(self._lib.stx_inlier_sum_dev(self._h, errors.data_ptr(), nh, n, float(threshold), inliers.data_ptr(),
+                                           err_sum.data_ptr()), "stx_inlier_sum_dev")
+
     # -- D ------------------------------------------------------------------
     def disparity(self, img0, img1, win=1, max_disp=0, cost_mode=COST_SAD, out_dtype=np.uint8, out=None):
         """out: optional C-contiguous [H,W] array of out_dtype to write into (a caller in a loop

@@ -12,8 +12,8 @@
 // Arithmetic: fp32, every multiply, add, divide and sqrt its own correctly rounded operation
 // (-ffp-contract=off); three-term sums of fixed-size Eigen expressions as a0 + (a1 + a2), Eigen's
 // unrolled reduction (the order the rectification kernel already follows).  The error sum of a
-// hypothesis is taken in pair order by a serial chain (fp32 addition does not reassociate), one
-// workgroup of two waves per hypothesis.
+// hypothesis is the one the serial loop gives, every addition rounded in pair order (fp32 addition does
+// not reassociate), but computed by parallel scans: see ransac_reduce_kernel.
 //
 // Bound: compute (about 30 IEEE divisions and square roots per evaluation); 16 B of pair data
 // in and 4 B of error out per evaluation.
@@ -256,126 +256,248 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_error_kernel(
     errors[o] = sqrtf(dot3(w0, w1, w2, w0, w1, w2));
 }
 
-// One workgroup of two waves per hypothesis: localInliers and the running avgError of :232-236.
-// fp32 addition does not reassociate, so the sum is a serial chain in pair order -- but only the
-// inliers are on it.  Per tile of RD_TILE errors (a) one wave compacts the inliers, in order,
-// into LDS with ballot / mbcnt prefix counts, all lanes working, while (b) the other wave runs
-// the chain over the previous tile's compacted values, every lane redundantly, sixteen values
-// per step with the next step's LDS reads in flight.  The next tile's global loads are issued
-// before (a), so neither wave waits on HBM once the pipeline runs.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+// localInliers and the running avgError of :232-236, one workgroup per hypothesis.
+//
+// fp32 addition does not reassociate, so the sum avgError += error, taken in pair order, looks like a
+// serial chain of n dependent additions (rounds 1 and 2 ran it as one: 0.4 ms for 200 x 200 000, as long
+// as the error kernel itself).  It is not.  While the running sum s stays inside one binade
+// [2^e, 2^(e+1)), s = M ulp with an integer M < 2^24, and fl(s + v) = (M + r) ulp where r is v / ulp
+// rounded to nearest -- a number that depends on v and e only, except on an exact tie (v / ulp =
+// k + 1/2), where round-to-even makes it k or k + 1 by the parity of M + k.  So every value is a map
+// "parity of M coming in -> advance of M", two integers (s0, s1); maps compose associatively (rd_then)
+// and a stretch of values collapses to one map by a parallel scan.  The assumption is checked, not
+// trusted: the first value at which M + r would reach 2^24 (the sum leaves the binade, or v is too large
+// for it) is found from the prefix maps, the eight values of that lane's run are added as floats, one
+// after the other, and the rest of the step is mapped again with the new exponent -- from the registers
+// it already sits in.  A sum of non-negative values leaves a binade only upwards, so at most 254 times
+// whatever the data are (a few dozen times for reprojection errors, most of them within the first few
+// hundred values): the kernel has no slow input.  Zero and denormal sums share the grid of the first
+// normal binade (ulp 2^-149; the float's bits ARE M there), an infinite sum absorbs every finite value
+// (all maps zero).  Ties are rare, so a wave whose tile has none scans plain integers instead of maps.
+// Results are those of the serial chain, bit for bit (tests/test_gpu_parity.py::test_inlier_sum_*: ties,
+// binade walks, zeros, denormals, overflow).
+constexpr int RD_WAVES = 8;                    // waves per hypothesis
+constexpr int RD_K = 8;                        // consecutive values per lane
+constexpr int RD_TILE = 64 * RD_K;             // values per wave and step
+constexpr int RD_STEP = RD_WAVES * RD_TILE;    // values per workgroup and step
+constexpr unsigned RD_OVER = 1u << 24;         // M + r >= RD_OVER: the binade ends here
+constexpr unsigned RD_SAT = 1u << 27;          // advances saturate (nothing behind an overflow is used)
 
-// (`sum` is tied into both asm blocks so that the adds between them stay between them)
-// reads the group that starts OFF bytes behind addr
-template <int OFF>
-__device__ __forceinline__ void lds_issue4(unsigned addr, f32x4 &r0, f32x4 &r1, f32x4 &r2, f32x4 &r3, float &sum)
+struct RdMap {
+    unsigned s0, s1;  // advance of M when M comes in even / odd
+};
+
+// a first, then b
+__device__ __forceinline__ RdMap rd_then(RdMap a, RdMap b)
 {
-    asm volatile("ds_read_b128 %0, %5 offset:%6\n\tds_read_b128 %1, %5 offset:%7\n\t"
-                 "ds_read_b128 %2, %5 offset:%8\n\tds_read_b128 %3, %5 offset:%9"
-                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "+v"(sum)
-                 : "v"(addr), "n"(OFF), "n"(OFF + 16), "n"(OFF + 32), "n"(OFF + 48)
-                 : "memory");
-}
-// the reads above are complete after this
-__device__ __forceinline__ void lds_wait(f32x4 &r0, f32x4 &r1, f32x4 &r2, f32x4 &r3, float &sum)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(sum));
-}
-__device__ __forceinline__ void chain16(float &sum, const f32x4 &v0, const f32x4 &v1, const f32x4 &v2,
-                                        const f32x4 &v3)
-{
-    sum = sum + v0.x; sum = sum + v0.y; sum = sum + v0.z; sum = sum + v0.w;
-    sum = sum + v1.x; sum = sum + v1.y; sum = sum + v1.z; sum = sum + v1.w;
-    sum = sum + v2.x; sum = sum + v2.y; sum = sum + v2.z; sum = sum + v2.w;
-    sum = sum + v3.x; sum = sum + v3.y; sum = sum + v3.z; sum = sum + v3.w;
+    RdMap c;
+    c.s0 = a.s0 + ((a.s0 & 1u) ? b.s1 : b.s0);
+    c.s1 = a.s1 + ((a.s1 & 1u) ? b.s0 : b.s1);
+    return c;
 }
 
-constexpr int RD_K = 8;               // values per lane per tile
-constexpr int RD_TILE = 64 * RD_K;
-
-__global__ __launch_bounds__(128) void ransac_reduce_kernel(const float *__restrict__ errors, int n, float threshold,
-                                                            int32_t *__restrict__ inliers,
-                                                            float *__restrict__ err_sum)
+__device__ __forceinline__ RdMap rd_saturated(RdMap c)
 {
-    // two waves per hypothesis: wave 1 compacts tile t into list[t & 1] while wave 0 runs the
-    // chain over tile t - 1 in the other buffer; one barrier per tile
-    __shared__ __align__(16) float list[2][RD_TILE + 48];
-    __shared__ int fill[2];
+    c.s0 = c.s0 < RD_SAT ? c.s0 : RD_SAT;
+    c.s1 = c.s1 < RD_SAT ? c.s1 : RD_SAT;
+    return c;
+}
+
+// q = v / ulp = (v * sa) * sb exactly (two powers of two: 1 / ulp alone is not always a float), capped
+// at 2^24, which ends the binade whatever M is; values that are no inliers leave M alone.
+__device__ __forceinline__ float rd_quotient(float v, bool in, float sa, float sb)
+{
+    const float q = fminf((fabsf(v) * sa) * sb, 0x1p24f);
+    return in ? q : 0.0f;
+}
+
+// the map of one value from its quotient and rn = rint(q), the even neighbour on a tie
+__device__ __forceinline__ RdMap rd_value(float q, float rn)
+{
+    const float other = (q + q) - rn;  // on a tie: the odd neighbour (2 q = 2 k + 1)
+    RdMap m;
+    m.s0 = (unsigned)rn;
+    m.s1 = (unsigned)(fabsf(q - rn) == 0.5f ? other : rn);
+    return m;
+}
+
+// the value of lane - 2^k (0 where there is none): row shifts, then the row broadcasts of a wave scan
+template <int CTRL, int ROWS>
+__device__ __forceinline__ unsigned rd_from_left(unsigned x)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWS, 0xF, false);
+}
+
+template <int CTRL, int ROWS>
+__device__ __forceinline__ void rd_scan_step(RdMap &a)
+{
+    RdMap l;
+    l.s0 = rd_from_left<CTRL, ROWS>(a.s0);
+    l.s1 = rd_from_left<CTRL, ROWS>(a.s1);
+    a = rd_saturated(rd_then(l, a));  // (0, 0) is the identity
+}
+
+// inclusive scan over the wave, in lane order: row_shr:1,2,4,8, row_bcast:15 into rows 1 and 3,
+// row_bcast:31 into rows 2 and 3
+__device__ __forceinline__ void rd_scan(RdMap &a)
+{
+    rd_scan_step<0x111, 0xF>(a);
+    rd_scan_step<0x112, 0xF>(a);
+    rd_scan_step<0x114, 0xF>(a);
+    rd_scan_step<0x118, 0xF>(a);
+    rd_scan_step<0x142, 0xA>(a);
+    rd_scan_step<0x143, 0xC>(a);
+}
+
+__device__ __forceinline__ unsigned rd_scan_sum(unsigned x, unsigned cap)
+{
+    auto sat = [cap](unsigned v) { return v < cap ? v : cap; };
+    x = sat(x + rd_from_left<0x111, 0xF>(x));
+    x = sat(x + rd_from_left<0x112, 0xF>(x));
+    x = sat(x + rd_from_left<0x114, 0xF>(x));
+    x = sat(x + rd_from_left<0x118, 0xF>(x));
+    x = sat(x + rd_from_left<0x142, 0xA>(x));
+    x = sat(x + rd_from_left<0x143, 0xC>(x));
+    return x;
+}
+
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // rows of `errors` start anywhere
+
+__global__ __launch_bounds__(RD_WAVES * 64) void ransac_reduce_kernel(const float *__restrict__ errors, int n,
+                                                                      float threshold,
+                                                                      int32_t *__restrict__ inliers,
+                                                                      float *__restrict__ err_sum)
+{
+    // inclusive prefix maps per lane, double buffered by pass (one barrier per pass)
+    __shared__ unsigned pm0[2][RD_WAVES][64], pm1[2][RD_WAVES][64];
+    __shared__ int wave_count[RD_WAVES];
     const int h = blockIdx.x, lane = threadIdx.x & 63;
-    const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 1;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const float *e = errors + (size_t)h * n;
-    const int tiles = (n + RD_TILE - 1) / RD_TILE;
-    float sum = 0.0f;
-    int count = 0;
-    float next[RD_K];
-    if (producer) {
+    const int myrun = wave * 64 + lane;  // this lane's run of RD_K values inside a step
+
+    auto load = [&](int base, float (&dst)[RD_K]) __attribute__((always_inline)) {
+        if (base + RD_K <= n) {
+            const f32x4u a = *reinterpret_cast<const f32x4u *>(e + base);
+            const f32x4u b = *reinterpret_cast<const f32x4u *>(e + base + 4);
+            dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
+            dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < RD_K; ++k) dst[k] = base + k < n ? e[base + k] : -1.0f;
+        }
+    };
+
+    // every thread carries the same (s, skip): functions of shared data only; the inliers are simply
+    // counted, each thread its own
+    float s = 0.0f;
+    int count = 0, pass = 0;
+    // One step: RD_STEP values from pos on, this thread's run of them in cur.
+    auto step = [&](int pos, const float (&cur)[RD_K]) __attribute__((always_inline)) {
+        // One pass per binade the sum visits inside this step (nearly always one): runs below `skip`
+        // have been added already.
+        int skip = 0;
+        bool in[RD_K];
 #pragma unroll
         for (int k = 0; k < RD_K; ++k) {
-            const int j = k * 64 + lane;
-            next[k] = j < n ? e[j] : -1.0f;
+            in[k] = cur[k] >= 0.0f && cur[k] < threshold;
+            count += in[k] ? 1 : 0;
         }
-    }
-    for (int t = 0; t <= tiles; ++t) {
-        if (producer) {
-            if (t < tiles) {
-                float cur[RD_K];
+        while (skip < RD_WAVES * 64) {
+            const unsigned sbits = __float_as_uint(s);
+            const int eb = (int)((sbits >> 23) & 0xffu);
+            const int grid = eb > 1 ? eb : 1;  // zero and denormal sums live on the grid of binade 1
+            // 1 / ulp = 2^(150 - grid) as two factors that are floats; inf and NaN sums absorb: q = 0
+            const int ea = 150 - grid > 100 ? 100 : 150 - grid < -100 ? -100 : 150 - grid;
+            const float sa = eb == 255 ? 0.0f : __uint_as_float((unsigned)(127 + ea) << 23);
+            const float sb = __uint_as_float((unsigned)(127 + (150 - grid - ea)) << 23);
+            const bool live = myrun >= skip;
+            float q[RD_K], rn[RD_K], far = 0.0f;
 #pragma unroll
-                for (int k = 0; k < RD_K; ++k) cur[k] = next[k];
-#pragma unroll
-                for (int k = 0; k < RD_K; ++k) {
-                    const int j = (t + 1) * RD_TILE + k * 64 + lane;
-                    next[k] = j < n ? e[j] : -1.0f;
-                }
-                // (a) in-order compaction of this tile's inliers
-                float *dst = list[t & 1];
-                int m = 0;
-#pragma unroll
-                for (int k = 0; k < RD_K; ++k) {
-                    const bool in = cur[k] >= 0.0f && cur[k] < threshold;
-                    const unsigned long long mask = __ballot(in);
-                    const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                    if (in) dst[m + before] = cur[k];
-                    m += __popcll(mask);
-                }
-                // whole groups are read; a group past the end is all +0, which leaves the
-                // (non-negative) sum as it is
-                if (lane < 48) dst[m + lane] = 0.0f;
-                if (lane == 0) fill[t & 1] = m;
+            for (int k = 0; k < RD_K; ++k) {
+                q[k] = rd_quotient(cur[k], live && in[k], sa, sb);
+                rn[k] = __builtin_rintf(q[k]);
+                far = fmaxf(far, fabsf(q[k] - rn[k]));
             }
-        } else if (t > 0) {
-            // (b) the chain, 16 values per group.  The next group's four LDS reads are issued
-            // BEFORE the current group's adds and waited for after them: written as asm because
-            // the compiler otherwise sinks the reads to their uses and every group pays the LDS
-            // round trip.
-            const int m = fill[(t - 1) & 1];
-            if (m > 0) {
-                const unsigned lbase =
-                    (unsigned)(size_t)(__attribute__((address_space(3))) float *)list[(t - 1) & 1];
-                const int groups = (m + 15) >> 4;
-                f32x4 a0, a1, a2, a3, b0, b1, b2, b3;
-                // (three groups of zeros follow the list, so the reads one and two groups ahead
-                // need no clamping: immediate offsets from one address that advances per step)
-                unsigned at = lbase;
-                lds_issue4<0>(at, a0, a1, a2, a3, sum);
-                lds_wait(a0, a1, a2, a3, sum);
-                for (int g = 0; g < groups; g += 2) {
-                    lds_issue4<64>(at, b0, b1, b2, b3, sum);
-                    chain16(sum, a0, a1, a2, a3);
-                    lds_wait(b0, b1, b2, b3, sum);
-                    lds_issue4<128>(at, a0, a1, a2, a3, sum);
-                    chain16(sum, b0, b1, b2, b3);
-                    lds_wait(a0, a1, a2, a3, sum);
-                    at += 128u;
-                }
-                count += m;
+            RdMap a = {0u, 0u};
+            if (!__any(far == 0.5f)) {  // no tie in this wave's tile: plain sums
+#pragma unroll
+                for (int k = 0; k < RD_K; ++k) a.s0 += (unsigned)rn[k];
+                a.s0 = a.s1 = rd_scan_sum(a.s0, RD_SAT);
+            } else {
+#pragma unroll
+                for (int k = 0; k < RD_K; ++k) a = rd_then(a, rd_value(q[k], rn[k]));
+                rd_scan(a);
             }
+            const int buf = pass & 1;
+            ++pass;
+            pm0[buf][wave][lane] = a.s0;
+            pm1[buf][wave][lane] = a.s1;
+            __syncthreads();
+
+            // M: the sum in units of its grid (the implicit bit only where there is one)
+            unsigned M = (sbits & 0x7fffffu) | (eb ? 0x800000u : 0u);
+            const unsigned below = (unsigned)(grid - 1) << 23;  // bits = below + M, for denormals too
+            int cw = -1;  // the wave whose tile holds the end of the binade
+#pragma unroll
+            for (int w = 0; w < RD_WAVES; ++w) {
+                if (cw < 0) {
+                    const unsigned adv = (M & 1u) ? pm1[buf][w][63] : pm0[buf][w][63];
+                    if (M + adv >= RD_OVER)
+                        cw = w;
+                    else
+                        M += adv;
+                }
+            }
+            if (cw < 0) {
+                s = __uint_as_float(below + M);
+                break;
+            }
+            const unsigned adv = (M & 1u) ? pm1[buf][cw][lane] : pm0[buf][cw][lane];
+            const unsigned long long over = __ballot(M + adv >= RD_OVER);  // lane 63 at least
+            const int ls = __builtin_ctzll(over);
+            if (ls > 0) M += (M & 1u) ? pm1[buf][cw][ls - 1] : pm0[buf][cw][ls - 1];
+            s = __uint_as_float(below + M);
+            // that lane's run as the reference adds it (an outlier adds +0: s + 0 = s)
+            const int run = __builtin_amdgcn_readfirstlane(cw * 64 + ls);
+            float v[RD_K];
+#pragma unroll
+            for (int k = 0; k < RD_K; ++k) {
+                const int j = pos + run * RD_K + k;
+                v[k] = j < n ? e[j] : -1.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < RD_K; ++k) s = s + (v[k] >= 0.0f && v[k] < threshold ? v[k] : 0.0f);
+            skip = run + 1;
         }
-        __syncthreads();
+    };
+    // three register sets in rotation: the loads of a step are issued two steps ahead of their use
+    // (copying the sets along would make every step wait for the loads it has just issued)
+    float b0[RD_K], b1[RD_K], b2[RD_K];
+    load(myrun * RD_K, b0);
+    load(RD_STEP + myrun * RD_K, b1);
+    for (int pos = 0; pos < n;) {
+        load(pos + 2 * RD_STEP + myrun * RD_K, b2);
+        step(pos, b0);
+        pos += RD_STEP;
+        if (pos >= n) break;
+        load(pos + 2 * RD_STEP + myrun * RD_K, b0);
+        step(pos, b1);
+        pos += RD_STEP;
+        if (pos >= n) break;
+        load(pos + 2 * RD_STEP + myrun * RD_K, b1);
+        step(pos, b2);
+        pos += RD_STEP;
     }
+    count = (int)rd_scan_sum((unsigned)count, 0xffffffffu);  // lane 63: the wave's inliers
+    if (lane == 63) wave_count[wave] = count;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        inliers[h] = count;
-        err_sum[h] = sum;
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < RD_WAVES; ++w) total += wave_count[w];
+        inliers[h] = total;
+        err_sum[h] = s;
     }
 }
 
@@ -432,7 +554,15 @@ int stx_launch_ransac_score(stx_ctx *ctx, const float *hyp, int n_hyp, const flo
                            d_errors, reinterpret_cast<float2 *>(d_depths));
         STX_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(ransac_reduce_kernel, dim3((unsigned)n_hyp), dim3(128), 0, ctx->stream, d_errors, n, threshold,
-                       d_inliers, d_err_sum);
+    return stx_launch_inlier_sum(ctx, d_errors, n_hyp, n, threshold, d_inliers, d_err_sum);
+}
+
+int stx_launch_inlier_sum(stx_ctx *ctx, const float *d_errors, int n_hyp, int n, float threshold,
+                          int32_t *d_inliers, float *d_err_sum)
+{
+    if (n_hyp <= 0) return STX_OK;
+    if (n > 0x7fffffff - 4 * RD_STEP) return STX_ERR_TOO_LARGE;  // (the kernel looks two steps ahead in int)
+    hipLaunchKernelGGL(ransac_reduce_kernel, dim3((unsigned)n_hyp), dim3(RD_WAVES * 64), 0, ctx->stream, d_errors, n,
+                       threshold, d_inliers, d_err_sum);
     return (int)hipGetLastError();
 }

@@ -1015,6 +1015,15 @@ extern "C" int stx_ransac_score_dev(stx_ctx *ctx, const float *hyp, int n_hyp, c
                                    d_err_sum, d_errors, d_depths);
 }
 
+extern "C" int stx_inlier_sum_dev(stx_ctx *ctx, const float *d_errors, int n_hyp, int n, float threshold,
+                                  int32_t *d_inliers, float *d_err_sum)
+{
+    if (!ctx || n_hyp < 0 || n < 0 || n_hyp > 65535) return STX_ERR_INVALID_ARG;
+    if (n_hyp > 0 && (!d_inliers || !d_err_sum || (n > 0 && !d_errors))) return STX_ERR_INVALID_ARG;
+    STX_ENTER(ctx);
+    return stx_launch_inlier_sum(ctx, d_errors, n_hyp, n, threshold, d_inliers, d_err_sum);
+}
+
 extern "C" int stx_ransac_score(stx_ctx *ctx, const float *hyp, int n_hyp, const float K1[9], const float K2[9],
                                 const float *p1, const float *p2, int n, const int32_t *exclude,
                                 float threshold, int32_t *inliers, float *err_sum, float *errors, float *depths)

@@ -177,6 +177,8 @@ int stx_launch_sift(stx_ctx *ctx, const uint8_t *d_gx, const uint8_t *d_gy, int 
 int stx_launch_cluster(stx_ctx *ctx, const float *d_xy, const float *d_score, int n, float window,
                        int32_t *d_index_out, int *d_count);
 
+int stx_launch_inlier_sum(stx_ctx *ctx, const float *d_errors, int n_hyp, int n, float threshold,
+                          int32_t *d_inliers, float *d_err_sum);
 int stx_launch_ransac_score(stx_ctx *ctx, const float *hyp, int n_hyp, const float K1[9], const float K2[9],
                             const float *d_p1, const float *d_p2, int n, const int32_t *exclude, float threshold,
                             int32_t *d_inliers, float *d_err_sum, float *d_errors, float *d_depths);

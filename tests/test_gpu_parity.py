@@ -1255,6 +1255,135 @@ def test_ransac_score_division_ranges(ctx, oracle):
             assert _same_f32(got[1], want[1]) and _same_f32(got[2], want[2]) and _same_f32(got[3], want[3]), (k, what)
 
 
+def _serial_inlier_sum(errors, thr):
+    """Stereography.cpp:232-236 restated for the test: localInliers and avgError += error in pair order,
+    every addition rounded to fp32 (ufunc.accumulate is the serial chain; checked against a Python loop
+    in tests/test_oracle_kat.py::test_accumulate_is_the_serial_fp32_chain)."""
+    counts, sums = [], []
+    with np.errstate(all="ignore"):
+        for row in errors:
+            v = row[(row >= 0) & (row < np.float32(thr))].astype(np.float32)
+            counts.append(len(v))
+            sums.append(np.add.accumulate(v, dtype=np.float32)[-1] if len(v) else np.float32(0))
+    return np.array(counts, np.int32), np.array(sums, np.float32)
+
+
+def _inlier_sum_gpu(ctx, errors, thr):
+    import torch
+    dev = torch.device("cuda", 0)
+    e = torch.from_numpy(np.ascontiguousarray(errors, np.float32)).to(dev)
+    inl = torch.full((e.shape[0],), -7, dtype=torch.int32, device=dev)
+    tot = torch.full((e.shape[0],), -7.0, dtype=torch.float32, device=dev)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.inlier_sum_dev(e, thr, inl, tot)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_stream(0)
+    return inl.cpu().numpy(), tot.cpu().numpy()
+
+
+def _check_inlier_sum(ctx, errors, thr, tag=None):
+    want = _serial_inlier_sum(errors, thr)
+    got = _inlier_sum_gpu(ctx, errors, thr)
+    assert np.array_equal(got[0], want[0]), tag
+    assert _same_f32(got[1], want[1]), (tag, got[1][:4], want[1][:4])
+    return want
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 511, 512, 513, 4095, 4096, 4097, 8200, 50_001])
+def test_inlier_sum_typical_rows(ctx, n):
+    """The in-order fp32 sum of the inliers, computed by parallel scans over maps of the mantissa
+    (ransac.hip), equals the serial chain bit for bit: reprojection-error-like rows of every ragged
+    length (odd n: rows start at any 4-byte address), several thresholds."""
+    rng = np.random.RandomState(n)
+    e = (rng.rand(9, n) * 140).astype(np.float32)
+    e[1] = rng.rand(n).astype(np.float32) ** 8 * 70            # mostly small
+    e[2, rng.rand(n) < 0.3] = -1                                 # excluded pairs
+    e[3, rng.rand(n) < 0.3] = 1000                               # failed triangulations
+    e[4, rng.rand(n) < 0.2] = np.nan
+    e[5] = 1000                                                  # no inlier at all
+    e[6, : n - n // 3] = 1000                                    # the first inlier comes late
+    e[7] = np.float32(0.1)                                       # one value over and over
+    e[8, ::2] = 0
+    for thr in (70.0, 2000.0, 1e-3, 0.0, np.inf):
+        want = _check_inlier_sum(ctx, e, thr, (n, thr))
+    assert want[0][0] == n
+
+
+def test_inlier_sum_ties_and_binade_ends(ctx):
+    """Rows built to sit on the rule's edges: additions that are exact ties at every step (round to even
+    by the parity of the running mantissa), sums that reach a power of two exactly, values of half an
+    ulp and just above or below it, and values that alone exceed the running sum."""
+    rng = np.random.RandomState(5)
+    n = 6000
+    rows = []
+    for start, unit in ((2.0 ** 23, 0.5), (2.0 ** 22, 0.25), (2.0 ** 20, 2.0 ** -4), (3 * 2.0 ** 21, 0.25),
+                        (2.0 ** 23 + 1, 0.5), (1.0, 2.0 ** -24), (1.0, 2.0 ** -25), (1.5, 2.0 ** -24)):
+        r = (rng.randint(0, 8, n) * unit).astype(np.float32)     # multiples of half an ulp: ties abound
+        r[0] = start
+        rows.append(r)
+        r2 = r.copy()
+        r2[1:] = unit * np.float32(1.0000001)                     # just above the tie
+        rows.append(r2)
+        r3 = r.copy()
+        r3[1:] = unit * np.float32(0.9999999)                     # just below
+        rows.append(r3)
+    r = np.full(n, 2.0 ** -3, np.float32)                         # sums hit 2^k exactly, then go on
+    rows.append(r)
+    r = (2.0 ** rng.randint(-30, 30, n)).astype(np.float32)      # powers of two all over: v > s happens often
+    rows.append(r)
+    r = np.cumsum(np.ones(n)).astype(np.float32)                  # 1, 2, 3, ...: the sum crosses binades early and late
+    rows.append(r)
+    r = (1.7 ** np.arange(n).clip(0, 150)).astype(np.float32)     # every value larger than the sum before it
+    rows.append(r)
+    e = np.stack(rows)
+    for thr in (np.inf, 3e38, 2.0 ** 24, 1.0, 0.3):
+        _check_inlier_sum(ctx, e, thr, thr)
+
+
+def test_inlier_sum_zeros_denormals_and_overflow(ctx):
+    """s = 0 and denormal sums (no integer mantissa to advance), -0, denormal values under a normal sum,
+    a sum that overflows to +inf and stays there."""
+    rng = np.random.RandomState(6)
+    n = 5000
+    tiny = np.float32(1e-45)
+    rows = [np.zeros(n, np.float32)]
+    r = np.zeros(n, np.float32); r[::3] = -0.0; r[4000] = 0.5; rows.append(r)
+    r = np.full(n, tiny, np.float32); rows.append(r)                                 # the sum stays denormal
+    r = (rng.randint(0, 1 << 22, n) * np.float64(tiny)).astype(np.float32); rows.append(r)   # denormals
+    r = (rng.randint(0, 1 << 23, n) * np.float64(tiny)).astype(np.float32); r[100] = 1.2e-38; rows.append(r)
+    r = (rng.rand(n) * 1e-38).astype(np.float32); rows.append(r)                     # around the smallest normal
+    r = (rng.rand(n) * 50).astype(np.float32); r[::5] = tiny; r[1::5] = 0; rows.append(r)
+    r = np.full(n, 3e38, np.float32); r[:100] = 1.0; rows.append(r)                  # overflows after two big ones
+    r = (rng.rand(n) * 3e38).astype(np.float32); rows.append(r)
+    r = np.zeros(n, np.float32); r[-1] = 7.25; rows.append(r)                        # the only inlier is the last value
+    r = np.full(n, -1, np.float32); r[-3] = 0.0; rows.append(r)
+    e = np.stack(rows)
+    for thr in (np.inf, 3.4e38, 70.0, 1e-38, 1e-44):
+        _check_inlier_sum(ctx, e, thr, thr)
+
+
+def test_inlier_sum_full_size_and_arguments(ctx):
+    """200 rows of 200 000: the size of the scoring step of BASELINE config 5; empty shapes; bad arguments."""
+    import torch
+    rng = np.random.RandomState(8)
+    e = (rng.rand(200, 200_000).astype(np.float32) ** 2 * 120).astype(np.float32)
+    e[rng.rand(200, 200_000) < 0.01] = -1
+    e[17] *= np.float32(1e-3)
+    e[18] *= np.float32(1e3)
+    want = _check_inlier_sum(ctx, e, 70.0)
+    assert want[0].max() > 100_000
+    got = _inlier_sum_gpu(ctx, np.zeros((3, 0), np.float32), 70.0)
+    assert got[0].tolist() == [0, 0, 0] and got[1].tolist() == [0, 0, 0]
+    got = _inlier_sum_gpu(ctx, np.zeros((0, 5), np.float32), 70.0)
+    assert len(got[0]) == 0
+    dev = torch.device("cuda", 0)
+    with pytest.raises(ValueError):
+        ctx.inlier_sum_dev(torch.zeros((2, 5), device=dev), 70.0, torch.zeros(3, dtype=torch.int32, device=dev),
+                           torch.zeros(2, device=dev))
+
+
 def test_ransac_score_empty_inputs(ctx):
     k = np.eye(3, dtype=np.float32)
     inl, tot = ctx.ransac_score(np.zeros((0, 36), np.float32), k, k, np.zeros((5, 2)), np.zeros((5, 2)))

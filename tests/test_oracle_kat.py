@@ -717,3 +717,18 @@ def test_ransac_golden_vectors(oracle):
     assert np.array_equal(err, g["errors"], equal_nan=True) and np.array_equal(dep, g["depths"], equal_nan=True)
     assert (g["errors"][5][g["errors"][5] >= 0] == 1000).all()      # the failed inner decomposition (:172)
     assert (g["errors"] == -1).sum() == 8 * 8 and g["inliers"].max() > 20
+
+
+def test_accumulate_is_the_serial_fp32_chain():
+    """tests/test_gpu_parity.py checks the GPU's in-order inlier sum (Stereography.cpp:232-236) against
+    np.add.accumulate in float32: that it is the serial chain s = fl(s + v), and not a pairwise or
+    widened sum, is checked here against an explicit loop."""
+    rng = np.random.RandomState(3)
+    for scale in (1.0, 1e-3, 1e6):
+        v = (rng.rand(20_000) * scale).astype(np.float32)
+        v[::7] = np.float32(0.5)
+        s = np.float32(0)
+        for x in v:
+            s = np.float32(s + x)
+        assert np.add.accumulate(v, dtype=np.float32)[-1].tobytes() == s.tobytes()
+        assert np.sum(v, dtype=np.float32).tobytes() != s.tobytes() or scale == 0   # (pairwise differs)
