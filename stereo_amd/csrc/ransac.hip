@@ -27,6 +27,7 @@ namespace {
 
 constexpr int RS_THREADS = 256;
 constexpr int RS_REC = 48;  // floats per device record
+constexpr int RS_HYP = 4;   // hypotheses per workgroup of the error kernel (RS_HYP * RS_REC <= RS_THREADS)
 
 // device record: E[9] Rinv[9] Rinv*t[3] R'[9] t'[3] ok exclude[8] pad
 struct Cams {
@@ -149,35 +150,13 @@ __device__ __forceinline__ float self_quotient(float x)
     return (x - x == 0.0f && x != 0.0f) ? 1.0f : __builtin_nanf("");
 }
 
-__global__ __launch_bounds__(RS_THREADS) void ransac_error_kernel(
-    const float *__restrict__ rec, Cams cams, const float2 *__restrict__ p1, const float2 *__restrict__ p2, int n,
-    float *__restrict__ errors, float2 *__restrict__ depths)
+// One (hypothesis, pair): ReprojectionError (:163-182) from the pair's rays x = K1^-1 p, y = K2^-1 p'
+// (:167-168, the same for every hypothesis) and the hypothesis record r; depth = Triangulate's two depths.
+__device__ __forceinline__ float pair_error(const float *r, const Cams &cams, float2 a1, float x0, float x1, float x2,
+                                            float y0, float y1, float y2, float2 &depth)
 {
-    __shared__ float r[RS_REC];
-    const int h = blockIdx.y;
-    if (threadIdx.x < RS_REC) r[threadIdx.x] = rec[(size_t)h * RS_REC + threadIdx.x];
-    __syncthreads();
-    const int i = blockIdx.x * RS_THREADS + threadIdx.x;
-    if (i >= n) return;
     const float *E = r, *Rinv = r + 9, *Rinvt = r + 18, *Rt = r + 21, *tt = r + 30;
-    const int *excl = reinterpret_cast<const int *>(r + 34);
-    bool skip = false;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) skip |= excl[k] == i;
-    const size_t o = (size_t)h * n + i;
     const float nanv = __builtin_nanf("");
-    if (skip) {
-        errors[o] = -1.0f;
-        if (depths) depths[o] = make_float2(nanv, nanv);
-        return;
-    }
-    const float2 a1 = p1[i], a2 = p2[i];
-    // :167-168
-    float x0 = row_dot3(cams.k1inv, 0, a1.x, a1.y, 1.0f), x1 = row_dot3(cams.k1inv, 1, a1.x, a1.y, 1.0f),
-          x2 = row_dot3(cams.k1inv, 2, a1.x, a1.y, 1.0f);
-    float y0 = row_dot3(cams.k2inv, 0, a2.x, a2.y, 1.0f), y1 = row_dot3(cams.k2inv, 1, a2.x, a2.y, 1.0f),
-          y2 = row_dot3(cams.k2inv, 2, a2.x, a2.y, 1.0f);
-
     // ---- LindstromOptimisation, :354-381 ------------------------------------
     {
         const float e00 = E[0], e01 = E[1], e10 = E[3], e11 = E[4];
@@ -237,11 +216,8 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_error_kernel(
             d1 = (a + b * d0) / c;
         }
     }
-    if (depths) depths[o] = ok ? make_float2(d0, d1) : make_float2(nanv, nanv);
-    if (!ok) {
-        errors[o] = 1000.0f;  // :172
-        return;
-    }
+    depth = ok ? make_float2(d0, d1) : make_float2(nanv, nanv);
+    if (!ok) return 1000.0f;  // :172
 
     // ---- ReprojectionError, :175-179 ----------------------------------------
     const float s0 = x0 * d1, s1 = x1 * d1, s2 = x2 * d1;
@@ -253,7 +229,57 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_error_kernel(
     t2 = self_quotient(z);
     const float w0 = row_dot3(cams.k2, 0, t0, t1, t2) - a1.x, w1 = row_dot3(cams.k2, 1, t0, t1, t2) - a1.y,
                 w2 = row_dot3(cams.k2, 2, t0, t1, t2) - 1.0f;
-    errors[o] = sqrtf(dot3(w0, w1, w2, w0, w1, w2));
+    return sqrtf(dot3(w0, w1, w2, w0, w1, w2));
+}
+
+__global__ __launch_bounds__(RS_THREADS) void ransac_error_kernel(
+    const float *__restrict__ rec, int n_hyp, Cams cams, const float2 *__restrict__ p1,
+    const float2 *__restrict__ p2, int n, float *__restrict__ errors, float2 *__restrict__ depths)
+{
+    // RS_HYP hypotheses per workgroup: the pair and its two rays are loaded and computed once, and a
+    // quarter as many workgroups stage records and start up (0.44 -> 0.41 ms at 200 x 200 000; 2, 4 and 5
+    // per workgroup measure the same).  The early `continue` below is worth 5 %: written as
+    // `err = skip ? -1 : pair_error(...)` with one store behind it, the kernel was that much slower.
+    __shared__ float recs[RS_HYP][RS_REC];
+    const int h0 = blockIdx.y * RS_HYP;
+    const int nh = n_hyp - h0 < RS_HYP ? n_hyp - h0 : RS_HYP;
+    if ((int)threadIdx.x < nh * RS_REC) (&recs[0][0])[threadIdx.x] = rec[(size_t)h0 * RS_REC + threadIdx.x];
+    __syncthreads();
+    const int i = blockIdx.x * RS_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float2 a1 = p1[i], a2 = p2[i];
+    const float nanv = __builtin_nanf("");
+    // :167-168
+    const float x0 = row_dot3(cams.k1inv, 0, a1.x, a1.y, 1.0f), x1 = row_dot3(cams.k1inv, 1, a1.x, a1.y, 1.0f),
+                x2 = row_dot3(cams.k1inv, 2, a1.x, a1.y, 1.0f);
+    const float y0 = row_dot3(cams.k2inv, 0, a2.x, a2.y, 1.0f), y1 = row_dot3(cams.k2inv, 1, a2.x, a2.y, 1.0f),
+                y2 = row_dot3(cams.k2inv, 2, a2.x, a2.y, 1.0f);
+#pragma unroll 1
+    for (int hh = 0; hh < nh; ++hh) {
+        const int h = h0 + hh;
+        // the chosen eight, which the reference erases before its loop (:205-211): read as scalars (a
+        // uniform address) and compared per lane only in the few workgroups whose 256 pairs hold one
+        // (the per-lane compare of all eight was 7 % of the kernel)
+        const int *excl = reinterpret_cast<const int *>(rec + (size_t)h * RS_REC + 34);
+        bool here = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) here |= excl[k] >= 0 && (unsigned)excl[k] / RS_THREADS == blockIdx.x;
+        bool skip = false;
+        if (here) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) skip |= excl[k] == i;
+        }
+        const size_t o = (size_t)h * n + i;
+        if (skip) {
+            errors[o] = -1.0f;
+            if (depths) depths[o] = make_float2(nanv, nanv);
+            continue;
+        }
+        float2 depth;
+        const float err = pair_error(recs[hh], cams, a1, x0, x1, x2, y0, y1, y2, depth);
+        if (depths) depths[o] = depth;
+        errors[o] = err;
+    }
 }
 
 // localInliers and the running avgError of :232-236, one workgroup per hypothesis.
@@ -548,8 +574,8 @@ int stx_launch_ransac_score(stx_ctx *ctx, const float *hyp, int n_hyp, const flo
     // the records were staged from pageable memory; wait so `rec` may go out of scope
     STX_HIP(hipStreamSynchronize(ctx->stream));
     if (n > 0) {
-        const dim3 grid((unsigned)((n + RS_THREADS - 1) / RS_THREADS), (unsigned)n_hyp);
-        hipLaunchKernelGGL(ransac_error_kernel, grid, dim3(RS_THREADS), 0, ctx->stream, d_rec, cams,
+        const dim3 grid((unsigned)((n + RS_THREADS - 1) / RS_THREADS), (unsigned)((n_hyp + RS_HYP - 1) / RS_HYP));
+        hipLaunchKernelGGL(ransac_error_kernel, grid, dim3(RS_THREADS), 0, ctx->stream, d_rec, n_hyp, cams,
                            reinterpret_cast<const float2 *>(d_p1), reinterpret_cast<const float2 *>(d_p2), n,
                            d_errors, reinterpret_cast<float2 *>(d_depths));
         STX_HIP(hipGetLastError());
