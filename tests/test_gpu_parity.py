@@ -1364,6 +1364,43 @@ def test_inlier_sum_zeros_denormals_and_overflow(ctx):
         _check_inlier_sum(ctx, e, thr, thr)
 
 
+def test_inlier_sum_random_structures(ctx):
+    """600 rows of 20 000 values drawn from generators that stress different parts of the rule: values
+    quantised to 2^-k (ties against sums of every size), exponents spread over 1 ... 80 binades, bursts
+    of large values, long runs of outliers, random bit patterns (NaN, inf, negative and denormal values
+    included), each with several thresholds."""
+    rng = np.random.RandomState(77)
+    n = 20_000
+    rows = []
+    for k in range(600):
+        kind = k % 6
+        if kind == 0:      # quantised: multiples of 2^-q up to 2^m
+            q, m = rng.randint(0, 12), rng.randint(1, 10)
+            r = rng.randint(0, 1 << (q + m), n) * 2.0 ** -q
+        elif kind == 1:    # log-uniform magnitudes over a random span of binades
+            span = rng.randint(1, 80)
+            r = 2.0 ** (rng.rand(n) * span - span / 2) * (1 + rng.rand(n))
+        elif kind == 2:    # small values with bursts of large ones
+            r = rng.rand(n) * 0.01
+            at = rng.randint(0, n, rng.randint(1, 40))
+            r[at] = rng.rand(len(at)) * 10.0 ** rng.randint(0, 8)
+        elif kind == 3:    # long stretches of outliers and excluded pairs
+            r = rng.rand(n) * 100
+            for _ in range(rng.randint(1, 6)):
+                a = rng.randint(0, n)
+                r[a:a + rng.randint(1, 9000)] = rng.choice([-1.0, 1000.0, np.nan])
+        elif kind == 4:    # random bit patterns
+            r = rng.randint(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+        else:              # halves and quarters of an ulp of a large first value
+            first = 2.0 ** rng.randint(-10, 30)
+            r = rng.randint(0, 5, n) * (first * 2.0 ** -(23 + rng.randint(0, 3)))
+            r[0] = first
+        rows.append(np.asarray(r, np.float32))
+    e = np.stack(rows)
+    for thr in (np.inf, 70.0, 1.0, 2.0 ** -20):
+        _check_inlier_sum(ctx, e, thr, thr)
+
+
 def test_inlier_sum_full_size_and_arguments(ctx):
     """200 rows of 200 000: the size of the scoring step of BASELINE config 5; empty shapes; bad arguments."""
     import torch
