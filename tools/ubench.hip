@@ -137,6 +137,54 @@ __device__ inline unsigned fold(u32x4 v) { return v.x ^ v.y ^ v.z ^ v.w; }
 #define L_MQSAD(D) "v_mqsad_pk_u16_u8 " D ", %8, %9, " D "\n"
 #define L_PERMLANE32(D) "v_permlane32_swap_b32 " D ", %8\n"
 
+#define L_MIN_F32(D) "v_min_f32 " D ", %8, " D "\n"
+#define L_MAX_F32(D) "v_max_f32 " D ", %8, " D "\n"
+#define L_MIN3_F32(D) "v_min3_f32 " D ", %8, %9, " D "\n"
+#define L_MAX3_F32(D) "v_max3_f32 " D ", %8, %9, " D "\n"
+#define L_MED3_F32(D) "v_med3_f32 " D ", %8, %9, " D "\n"
+#define L_MUL_F32(D) "v_mul_f32 " D ", %8, " D "\n"
+#define L_ADD_F32(D) "v_add_f32 " D ", %8, " D "\n"
+#define L_MOV_B32(D) "v_mov_b32 " D ", %8\n"
+#define L_AND_B32(D) "v_and_b32 " D ", %8, " D "\n"
+#define L_OR_B32(D) "v_or_b32 " D ", %8, " D "\n"
+#define L_XOR_B32(D) "v_xor_b32 " D ", %8, " D "\n"
+#define L_LSHLREV(D) "v_lshlrev_b32 " D ", 3, " D "\n"
+#define L_LSHL_ADD(D) "v_lshl_add_u32 " D ", %8, 16, " D "\n"
+#define L_MIN_I32(D) "v_min_i32 " D ", %8, " D "\n"
+#define L_SUBREV_U32(D) "v_subrev_u32 " D ", %8, " D "\n"
+#define L_MUL_U24(D) "v_mul_u32_u24 " D ", %8, " D "\n"
+#define L_DOT4_U8(D) "v_dot4_u32_u8 " D ", %8, %9, " D "\n"
+#define L_ADD_CO(D) "v_add_co_u32 " D ", vcc, %8, " D "\n"
+#define L_ADDC_CO(D) "v_addc_co_u32 " D ", vcc, " D ", " D ", vcc\n"
+#define L_CMP_NLT_F32(D) "v_cmp_nlt_f32 vcc, %8, " D "\n"
+#define L_RNDNE(D) "v_rndne_f32 " D ", " D "\n"
+#define L_CVT_U32_F32(D) "v_cvt_u32_f32 " D ", " D "\n"
+#define L_PK_ADD_F32(D) "v_pk_add_f32 " D ", %8, " D "\n"
+#define L_PK_MUL_F32(D) "v_pk_mul_f32 " D ", %8, " D "\n"
+UB32(k_min_f32, L_MIN_F32)
+UB32(k_max_f32, L_MAX_F32)
+UB32(k_min3_f32, L_MIN3_F32)
+UB32(k_max3_f32, L_MAX3_F32)
+UB32(k_med3_f32, L_MED3_F32)
+UB32(k_mul_f32, L_MUL_F32)
+UB32(k_add_f32, L_ADD_F32)
+UB32(k_mov_b32, L_MOV_B32)
+UB32(k_and_b32, L_AND_B32)
+UB32(k_or_b32, L_OR_B32)
+UB32(k_xor_b32, L_XOR_B32)
+UB32(k_lshlrev, L_LSHLREV)
+UB32(k_lshl_add, L_LSHL_ADD)
+UB32(k_min_i32, L_MIN_I32)
+UB32(k_subrev_u32, L_SUBREV_U32)
+UB32(k_mul_u24, L_MUL_U24)
+UB32(k_dot4_u8, L_DOT4_U8)
+UB32(k_add_co, L_ADD_CO)
+UB32(k_addc_co, L_ADDC_CO)
+UB32(k_cmp_nlt_f32, L_CMP_NLT_F32)
+UB32(k_rndne, L_RNDNE)
+UB32(k_cvt_u32_f32, L_CVT_U32_F32)
+UB64(k_pk_add_f32, L_PK_ADD_F32)
+UB64(k_pk_mul_f32, L_PK_MUL_F32)
 UB32(k_sad_u32, L_SAD_U32)
 UB32(k_sad_u32_s, L_SAD_U32_S)
 UB32(k_min_u32, L_MIN_U32)
@@ -215,6 +263,10 @@ int main(int argc, char **argv)
            prop.sharedMemPerBlock);
     std::vector<Entry> es = {
 #define E(n) {#n, n}
+        E(k_min_f32), E(k_max_f32), E(k_min3_f32), E(k_max3_f32), E(k_med3_f32), E(k_mul_f32), E(k_add_f32),
+        E(k_mov_b32), E(k_and_b32), E(k_or_b32), E(k_xor_b32), E(k_lshlrev), E(k_lshl_add), E(k_min_i32),
+        E(k_subrev_u32), E(k_mul_u24), E(k_dot4_u8), E(k_add_co), E(k_addc_co), E(k_cmp_nlt_f32), E(k_rndne),
+        E(k_cvt_u32_f32), E(k_pk_add_f32), E(k_pk_mul_f32),
         E(k_fma_f32), E(k_pk_fma_f32), E(k_add_u32), E(k_sub_u32), E(k_add3_u32), E(k_min_u32), E(k_max_u32),
         E(k_min3_u32), E(k_sad_u32), E(k_sad_u32_s), E(k_sad_u8), E(k_msad_u8), E(k_sad_u16),
         E(k_qsad), E(k_mqsad), E(k_lshl_or), E(k_and_or), E(k_bfe), E(k_bfi), E(k_perm),
