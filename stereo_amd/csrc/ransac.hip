@@ -80,10 +80,11 @@ __device__ __forceinline__ float col_dot3_seq(const float *m, int c, float v0, f
 // When |n| and |d| lie in [2^-40, 2^40] neither v_div_scale rescales anything, v_div_fmas is a plain
 // fma and v_div_fixup returns its input, so the same fma chain without those three instructions gives
 // the same bits (the argument and the guard of divide_pair in rectify.hip, whose test walks the
-// guard's limits); the reciprocal and its Newton step are shared, two chains run as packed fp32.
-// Lanes outside the range take the compiler's full divide.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
+// guard's limits); the reciprocal and its Newton step are shared.  Lanes outside the range take the
+// compiler's full divide.  Scalar fp32 throughout, and the file is built with -fno-slp-vectorize: on gfx950
+// v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 issue at 2.77 cycles per SIMD against 1.49 - 1.63 for the
+// scalar forms (profiles/r03_ubench_instruction_rates_more.txt), so a packed pair saves nothing and the
+// v_mov_b32 that assemble its operands are pure cost: 0.49 -> 0.42 ms for the scoring call.
 __device__ __forceinline__ bool div_in_range(float lo, float hi) { return lo >= 0x1p-40f && hi <= 0x1p40f; }
 
 __device__ __forceinline__ float shared_rcp(float d)
@@ -91,16 +92,6 @@ __device__ __forceinline__ float shared_rcp(float d)
     float r = __builtin_amdgcn_rcpf(d);
     const float e = __builtin_fmaf(-d, r, 1.0f);
     return __builtin_fmaf(e, r, r);
-}
-
-__device__ __forceinline__ f32x2 quot2(f32x2 n, float d, float r)
-{
-    const f32x2 nd = {-d, -d}, rr = {r, r};
-    f32x2 t = n * rr;
-    f32x2 res = __builtin_elementwise_fma(nd, t, n);
-    t = __builtin_elementwise_fma(res, rr, t);
-    res = __builtin_elementwise_fma(nd, t, n);
-    return __builtin_elementwise_fma(res, rr, t);
 }
 
 __device__ __forceinline__ float quot1(float n, float d, float r)
@@ -117,9 +108,9 @@ __device__ __forceinline__ void divide2(float &n0, float &n1, float d)
 {
     const float a0 = fabsf(n0), a1 = fabsf(n1), ad = fabsf(d);
     if (div_in_range(fminf(fminf(a0, a1), ad), fmaxf(fmaxf(a0, a1), ad))) {
-        const f32x2 q = quot2(f32x2{n0, n1}, d, shared_rcp(d));
-        n0 = q.x;
-        n1 = q.y;
+        const float r = shared_rcp(d);
+        n0 = quot1(n0, d, r);
+        n1 = quot1(n1, d, r);
     } else {
         n0 = n0 / d;
         n1 = n1 / d;
@@ -132,9 +123,8 @@ __device__ __forceinline__ void divide3(float &n0, float &n1, float &n2, float d
     const float a0 = fabsf(n0), a1 = fabsf(n1), a2 = fabsf(n2), ad = fabsf(d);
     if (div_in_range(fminf(fminf(a0, a1), fminf(a2, ad)), fmaxf(fmaxf(a0, a1), fmaxf(a2, ad)))) {
         const float r = shared_rcp(d);
-        const f32x2 q = quot2(f32x2{n0, n1}, d, r);
-        n0 = q.x;
-        n1 = q.y;
+        n0 = quot1(n0, d, r);
+        n1 = quot1(n1, d, r);
         n2 = quot1(n2, d, r);
     } else {
         n0 = n0 / d;
