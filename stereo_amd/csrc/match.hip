@@ -350,6 +350,7 @@ constexpr int MF_TJ = 2;               // row blocks per LDS tile
 constexpr int MF_TILE_ROWS = MF_JB * MF_TJ;
 constexpr int MF_BLOCK_FLOATS = MF_JB * K;  // 4096 floats = 16 KiB per row block
 constexpr int MF_CAP = 256;            // candidates per query that the replay kernel sorts
+constexpr size_t MF_LIST_BYTES = (size_t)2 << 30;  // what the x1 kernel's candidate lists may take
 constexpr float MF_C = 6.103515625e-05f;  // 2^-14 >= 523 * 2^-24
 constexpr float MF_TINY = 1e-37f;      // covers underflow in either computation
 
@@ -1749,7 +1750,20 @@ int stx_launch_match(stx_ctx *ctx, const float *d_desc1, const float *d_score1, 
     // candidate lists: one list of MF_CAP slots per query filled with atomics (fp32 / bf16x3
     // kernels), or two private sub-lists per piece (x1 kernel)
     const int nsub = x1 ? 2 * max_pieces + 1 : 1;  // x1: + the warm kernel's list
-    const int subcap = x1 ? (nsub <= 8 ? 128 : nsub <= 16 ? 64 : 32) : MF_CAP;
+    // Slots per sub-list.  A sub-list that overflows sends its query to the overflow pass (an exact scan
+    // of all of list2: 2.4 us per such query at n2 = 200 000), a slot that stays empty costs nothing but
+    // address space, so the lists take what MF_LIST_BYTES allows (512 slots at 200k x 200k, 2 GB of the
+    // 288): a cluster of ~500 near-identical rows then stays in its lists (clustered 200k x 200k:
+    // 1 223 overflowing queries and 2.9 ms of overflow pass before).  STX_MATCH_SUBCAP (tests only)
+    // forces a value, so that small shapes still reach the overflow pass.
+    int subcap = MF_CAP;
+    if (x1) {
+        subcap = nsub <= 8 ? 128 : nsub <= 16 ? 64 : 32;
+        const size_t fit = MF_LIST_BYTES / (sizeof(int) * (size_t)n1 * (size_t)nsub);
+        while (subcap < 1024 && (size_t)subcap * 2 <= fit) subcap *= 2;
+        const char *forced = getenv("STX_MATCH_SUBCAP");
+        if (forced && atoi(forced) >= 8 && atoi(forced) <= 4096) subcap = atoi(forced);
+    }
     // [count n1*nsub][overflow_count 1 (+pad)][overflow_list n1][cand n1*nsub*subcap]
     const size_t n1a = ((size_t)n1 + 3) & ~(size_t)3;
     const size_t ncnt = ((size_t)n1 * nsub + 3) & ~(size_t)3;

@@ -115,26 +115,37 @@ def test_config5_full_size_200k_x_200k(ctx, oracle):
 _config5_times = {}
 
 
-def test_config5_clustered_200k_x_200k(ctx, oracle):
+def test_config5_clustered_200k_x_200k(ctx, oracle, monkeypatch):
     """Config 5's size on descriptors with repeated structure: 2 000 centres with
     ~100 near-duplicates each at noise 1e-3, and two centres with ~500 each.  Near-ties pile up in the
-    running-minimum scan: ~130 candidates per query instead of ~30, and the ~1 000 queries of the two
-    large clusters overflow their candidate lists and take the overflow pass (the exact scan cut along
-    list2).  Bit-exact on a sample that holds overflowing and ordinary queries, and the whole call
-    stays within 3x of the ordinary set's time (it was a cliff: one lane per overflowing query)."""
+    running-minimum scan: ~120 candidates per query instead of ~30.  With the sub-lists at their default
+    size (512 slots at this shape) even the two large clusters stay in their lists; held to 128 slots
+    (round 3's first version) their ~1 000 queries overflow and take the overflow pass, the exact scan
+    cut along list2.  Bit-exact both ways on a sample that holds queries of the large clusters and
+    ordinary ones; the call stays within 2x (3x with the overflow pass) of the ordinary set's time --
+    it was a cliff: one lane per overflowing query."""
     n = 200_000
     d1, s1, d2, s2, w1, _ = synth.descriptor_sets_clustered(77, n, n, with_clusters=True)
     hot = np.nonzero(w1 < 2)[0]                      # queries of the two large clusters (and their small share)
     assert len(hot) > 800
     idx = np.unique(np.concatenate([np.arange(0, n, 131)[:1500], hot[:200], [0, 1, 511, 512, n - 1]]))
-    got, _, stats, ms = _config5_run(ctx, oracle, d1, s1, d2, s2, idx)
-    assert stats["queries"] == n and stats["overflow_queries"] > 100, stats
-    assert stats["candidates_per_query"] > 60, stats
-    print("clustered 200k x 200k: %.2f ms, %s" % (ms, stats))
     base = _config5_times.get("synthetic")
+    got, _, stats, ms = _config5_run(ctx, oracle, d1, s1, d2, s2, idx)
+    assert stats["queries"] == n and stats["overflow_queries"] == 0, stats
+    assert stats["candidates_per_query"] > 60 and stats["candidates_max"] > 400, stats
+    print("clustered 200k x 200k: %.2f ms, %s" % (ms, stats))
     if base is not None:
-        assert ms < 3.0 * base, (ms, base)
-    assert ms < 40.0, ms
+        assert ms < 2.0 * base, (ms, base)
+    assert ms < 30.0, ms
+    monkeypatch.setenv("STX_MATCH_SUBCAP", "128")
+    got2, _, stats2, ms2 = _config5_run(ctx, oracle, d1, s1, d2, s2, idx)
+    assert stats2["queries"] == n and stats2["overflow_queries"] > 100, stats2
+    print("clustered 200k x 200k, 128-slot sub-lists: %.2f ms, %s" % (ms2, stats2))
+    for a_, b_ in zip(got, got2):
+        assert np.array_equal(a_, b_, equal_nan=True) if a_.dtype.kind == "f" else np.array_equal(a_, b_)
+    if base is not None:
+        assert ms2 < 3.0 * base, (ms2, base)
+    assert ms2 < 40.0, ms2
 
 
 # ------------------------------------------------------------------ config 4 ----

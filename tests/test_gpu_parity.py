@@ -727,10 +727,12 @@ def test_match_non_finite_and_extreme_values(ctx, oracle, algo):
 
 
 @pytest.mark.parametrize("algo", [api.MATCH_MFMA, api.MATCH_MFMA_BF16, api.MATCH_MFMA_BF16X1])
-def test_match_candidate_overflow_goes_to_exact_scan(ctx, oracle, algo):
+def test_match_candidate_overflow_goes_to_exact_scan(ctx, oracle, algo, monkeypatch):
     """list2 ordered so that (almost) every row is a new running minimum for the first queries:
     their candidate lists overflow (atomic lists and private sub-lists alike) and the exact
-    kernel redoes them; the other queries keep short lists."""
+    kernel redoes them; the other queries keep short lists.  (STX_MATCH_SUBCAP: the sub-lists of
+    the x1 kernel would hold these 1 500 rows at their default size.)"""
+    monkeypatch.setenv("STX_MATCH_SUBCAP", "32")
     rng = np.random.RandomState(5)
     n1, n2 = 70, 1500
     base = np.abs(rng.randn(128)).astype(np.float32)
@@ -755,13 +757,15 @@ def test_match_candidate_overflow_goes_to_exact_scan(ctx, oracle, algo):
 
 
 @pytest.mark.parametrize("n1,n2,hot", [(70, 1500, 9), (5000, 1500, 5000), (300, 40000, 130), (9000, 3000, 4500)])
-def test_match_overflow_pass_cuts_list2_into_segments(ctx, oracle, n1, n2, hot):
+def test_match_overflow_pass_cuts_list2_into_segments(ctx, oracle, n1, n2, hot, monkeypatch):
     """The overflow pass (match_exact_seg_kernel + match_exact_merge_kernel): `hot` queries sit next to a
     vector that list2's rows approach steadily, so (almost) every row is a record for them and their
     lists overflow.  The number of overflowing queries decides, on the device, how many segments
     list2 is cut into (2048 short ones for a handful, one per wave for thousands), so both ends and
     the middle are covered; NaN at row 0, +inf rows, and equal rows either side of segment borders
-    ride along."""
+    ride along.  The sub-lists are held to 32 slots (STX_MATCH_SUBCAP, what these shapes had before the
+    lists were sized by a memory budget): at their default size the short list2's of this test would fit."""
+    monkeypatch.setenv("STX_MATCH_SUBCAP", "32")
     rng = np.random.RandomState(n1 + n2)
     base = np.abs(rng.randn(128)).astype(np.float32)
     base /= np.linalg.norm(base)
@@ -808,8 +812,8 @@ def test_match_overflow_pass_cuts_list2_into_segments(ctx, oracle, n1, n2, hot):
 def test_match_long_candidate_lists_are_replayed_in_place(ctx, oracle):
     """More candidates than the replay kernel's LDS arrays hold (256) but no sub-list overflow: a cluster
     of ~315 near-identical rows spread over list2 lands in a query's four to six sub-lists, some 80
-    each (capacity 128 at this shape); the replay walks the lists in place and recomputes the
-    distances for `second`.  No query may take the overflow pass."""
+    each; the replay walks the lists in place and recomputes the distances for `second`.  No query may
+    take the overflow pass."""
     n1, n2 = 66000, 9000
     d1, s1, d2, s2 = synth.descriptor_sets_clustered(31, n1, n2, centres=200, noise=1e-3, big_frac=0.035, big=1)
     ctx.set_match_algo(api.MATCH_MFMA_BF16X1)
