@@ -109,7 +109,15 @@ tc = [torch.from_numpy(a).cuda() for a in (c1, cs1, c2, cs2)]
 run("match_x1_prefilter_200k_clustered", "match_mfma_bf16x1_kernel", 1,
     lambda: ctx.match_dev(tc[0], tc[1], tc[2], tc[3], 1000.0, oc, os_, om, od, ot))
 order.append({"key": "match_replay_200k_clustered", "kernel": "match_replay_kernel", "launches_per_call": 1, "calls": CALLS})
+order.append({"key": "match_overflow_scan_200k_clustered_none_overflows", "kernel": "match_exact_seg_kernel", "launches_per_call": 1, "calls": CALLS})
+# ... and with the candidate sub-lists held to 128 slots, so that the two large clusters overflow
+# and the overflow pass has its 1 223 queries to scan
+os.environ["STX_MATCH_SUBCAP"] = "128"
+run("match_x1_prefilter_200k_clustered_128slots", "match_mfma_bf16x1_kernel", 1,
+    lambda: ctx.match_dev(tc[0], tc[1], tc[2], tc[3], 1000.0, oc, os_, om, od, ot))
+order.append({"key": "match_replay_200k_clustered_128slots", "kernel": "match_replay_kernel", "launches_per_call": 1, "calls": CALLS})
 order.append({"key": "match_overflow_scan_200k_clustered", "kernel": "match_exact_seg_kernel", "launches_per_call": 1, "calls": CALLS})
+del os.environ["STX_MATCH_SUBCAP"]
 out = os.environ.get("PMC_OUT") or os.path.join(ROOT, "gpurun_out", "pmc_r03")
 os.makedirs(out, exist_ok=True)
 json.dump(order, open(os.path.join(out, "workloads.json"), "w"), indent=1)
