@@ -573,6 +573,16 @@ def test_no_page_locked_memory_falls_back_to_plain_copies(oracle, monkeypatch):
         _match_equal(c.match(p1.numpy(), s1, p2.numpy(), s2, 1000.0), wantm)
         got = c.staging_bytes()
         assert 0 < got <= 2 << 20
+        # mixed: one list page-locked, the other staged (its staging starts where the first one's would end)
+        monkeypatch.delenv("STX_PIN_LIMIT_MB")
+        _match_equal(c.match(p1.numpy(), s1, d2, s2, 1000.0), wantm)
+        _match_equal(c.match(d1, s1, p2.numpy(), s2, 1000.0), wantm)
+        q1 = torch.from_numpy(r1.view(np.uint8).reshape(n1, -1)).pin_memory()
+        q2 = torch.from_numpy(r2.view(np.uint8).reshape(n2, -1)).pin_memory()
+        f1, f2 = q1.numpy().view(feature).reshape(n1), q2.numpy().view(feature).reshape(n2)
+        _match_equal(c.match_features(f1, f2, 20, 12, 1000.0), wantm)
+        _match_equal(c.match_features(f1, r2, 20, 12, 1000.0), wantm)
+        _match_equal(c.match_features(r1, f2, 20, 12, 1000.0), wantm)
     finally:
         c.close()
 
