@@ -809,6 +809,39 @@ def test_match_overflow_pass_cuts_list2_into_segments(ctx, oracle, n1, n2, hot, 
         _match_equal(got, want)
 
 
+def test_match_prefilter_against_exact_scan_random_shapes(ctx):
+    """Seeded differential run over shapes nobody picked by hand: few to many query blocks, short to long
+    list2 (one piece per tile up to two pieces per query block), ordinary and clustered descriptors; the
+    prefilter + replay must give the exact GPU scan's five outputs bit for bit.  (The exact scan is pinned
+    to the oracle by the tests above; tools/exp/match_fuzz.py runs more rounds.)"""
+    import torch
+    rng = np.random.RandomState(4711)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        for k in range(14):
+            n1 = int(2 ** rng.uniform(6, 15.5))
+            n2 = int(2 ** rng.uniform(9, 16.5))
+            if k % 3 == 2:
+                d1, s1, d2, s2 = synth.descriptor_sets_clustered(
+                    k, n1, n2, centres=max(2, n2 // int(2 ** rng.uniform(3, 9))), noise=10.0 ** rng.uniform(-4, -2))
+            else:
+                d1, s1, d2, s2 = synth.descriptor_sets(k, n1, n2)
+            t = [torch.from_numpy(a).cuda() for a in (d1, s1, d2, s2)]
+            res = []
+            for algo in (api.MATCH_MFMA_BF16X1, api.MATCH_EXACT):
+                o = [torch.empty(n1, dtype=dt, device="cuda")
+                     for dt in (torch.int32, torch.int32, torch.float32, torch.float32, torch.uint8)]
+                ctx.set_match_algo(algo)
+                ctx.match_dev(t[0], t[1], t[2], t[3], 1000.0, *o)
+                torch.cuda.synchronize()
+                res.append(o)
+            for a, b in zip(*res):
+                assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), (k, n1, n2)
+    finally:
+        ctx.set_match_algo(api.MATCH_AUTO)
+        ctx.set_stream(0)
+
+
 def test_match_long_candidate_lists_are_replayed_in_place(ctx, oracle):
     """More candidates than the replay kernel's LDS arrays hold (256) but no sub-list overflow: a cluster
     of ~315 near-identical rows spread over list2 lands in a query's four to six sub-lists, some 80
