@@ -99,6 +99,31 @@ def test_disparity_ext_matches_oracle(ctx, oracle, win, D, cm, algo):
     assert (got == want).all(), np.argwhere(got != want)[:10]
 
 
+def test_disparity_random_shapes_three_kernels_and_oracle(ctx, oracle):
+    """Seeded run over shapes, windows, disparity counts, costs and output widths nobody picked by hand:
+    the register sliding-sum kernel (what AUTO picks), the LDS column-sum kernel and the tap-by-tap kernel
+    must agree with the sliding oracle and with each other, bit for bit."""
+    rng = np.random.RandomState(99)
+    for k in range(24):
+        win = int(rng.choice([1, 3, 5, 7, 9, 11, 13, 15, 17, 21, 25, 31]))
+        h = int(rng.randint(win + 1, 90))
+        w = int(2 ** rng.uniform(5, 10.6))
+        D = int(min(w, 2 ** rng.uniform(0, 9.5)))
+        cm = int(rng.randint(0, 2))
+        dt = np.uint16 if (D > 256 or rng.rand() < 0.3) else np.uint8
+        a, b = _rand_pair(1000 + k, h, w, zero=0.02)
+        want = oracle.disparity_ext(a, b, win, D, cm, dt, sliding=True)
+        for algo in (api.DISP_AUTO, api.DISP_COLSUM, api.DISP_BRUTEFORCE):
+            if algo == api.DISP_BRUTEFORCE and (win > 15 or h * w * D > 3e7):
+                continue
+            ctx.set_disparity_algo(algo)
+            try:
+                got = ctx.disparity(a, b, win=win, max_disp=D, cost_mode=cm, out_dtype=dt)
+            finally:
+                ctx.set_disparity_algo(api.DISP_AUTO)
+            assert (got == want).all(), (k, win, h, w, D, cm, dt, algo, np.argwhere(got != want)[:5])
+
+
 @pytest.mark.parametrize("win", [1, 3, 5, 7, 9, 11, 13, 15])
 @pytest.mark.parametrize("h,w,D", [(40, 300, 16), (130, 520, 100), (70, 777, 256), (33, 1100, 300),
                                    (20, 900, 700)])
